@@ -1,0 +1,371 @@
+// rt_core.h -- the per-ray and per-path-vertex arithmetic of the kernels,
+// written as host/device inline functions so that the HIP kernels
+// (rt_kernels.hip) and a lane-serial CPU harness used by the unit tests
+// compile the very same code.
+//
+// Reference semantics implemented here (paths under src/backend/):
+//   models/ray.go:23-42        ray set-up (invDir, sign)
+//   models/aabb.go:62-99       slab test, compare-and-assign form
+//   models/triangle.go:78-103  one-sided Moller-Trumbore, det < 1e-4
+//   models/bvh.go:117-144      WalkNode order: left subtree completely before
+//                              the right child's box is tested, strict '<'
+//   process/trace.go:44-109    per-vertex shading / bounce arithmetic
+//   utility/utility.go:34-70   ClampColor, RandomInHemisphere
+//   models/arealight.go:42-56  AreaLight.Sample
+//   models/camera.go:99-129    GetCameraRay
+//   main.go:158-182            resolve
+// Build with -ffp-contract=off: the reference's float32 operations are never
+// fused, and the bit-exact modes depend on it.
+#pragma once
+
+#include <cstdint>
+
+#include "gomath.h"
+
+namespace rtc {
+
+constexpr float kF32Max = 3.40282346638528859811704183484516925440e+38f;
+
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+RT_HD int f2i(float f) {
+    union { float f; int i; } c;
+    c.f = f;
+    return c.i;
+}
+RT_HD float i2f(int i) {
+    union { float f; int i; } c;
+    c.i = i;
+    return c.f;
+}
+
+// ---------------------------------------------------------------------------
+// Flattened scene, resident in HBM.
+//
+// nodes: 2 x f4 per node, preorder (BVHNode.Index order).  The reference walks
+// left-child-first and tests a child's box from its parent; in preorder that is
+// "test node i; on pass continue at i+1, on fail jump past i's subtree".  Each
+// node therefore stores its own box plus that jump target ("skip"):
+//   [0] = (min.x, min.y, min.z, bits(a))   [1] = (max.x, max.y, max.z, bits(b))
+//   interior: a = skip index, b = -1       leaf: a = first triangle, b = count
+// tris: 3 x f4 per triangle in sorted-array order:
+//   [0] = (N.x, N.y, N.z, V0.x) [1] = (V0.y, V0.z, E0.x, E0.y) [2] = (E0.z, W.x, W.y, W.z)
+//   with W = v0v2 = Edge2 * -1.
+// ---------------------------------------------------------------------------
+struct DevScene {
+    const f4 *nodes;
+    const f4 *tris;
+    const int32_t *tri_mat;     // material id, bit 30 set when the material is "Light"
+    const float *kd;            // n_materials * 3
+    const float *tri_uv;        // n_tris * 6 or nullptr
+    const int32_t *mat_tex;     // n_materials texture slot or -1 (nullptr: none)
+    const uint8_t *const *tex_data;   // per slot RGBA8 rows
+    const int32_t *tex_dim;     // per slot (w, h)
+    const double *cam_tab;      // n_cam * 2
+    const double *light_tab;    // n_light * 2
+    int32_t n_nodes, n_tris, n_cam, n_light;
+};
+
+constexpr int32_t kLightBit = 1 << 30;
+
+// ---------------------------------------------------------------------------
+// Ray state for the reference-order traversal.
+// ---------------------------------------------------------------------------
+template <typename Real>
+struct Ray {
+    Real ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    bool sx, sy, sz;
+};
+
+template <typename Real>
+RT_HD void ray_init(Ray<Real> &r, float ox, float oy, float oz, float dx, float dy, float dz) {
+    r.ox = (Real)ox; r.oy = (Real)oy; r.oz = (Real)oz;
+    r.dx = (Real)dx; r.dy = (Real)dy; r.dz = (Real)dz;
+    r.ix = (Real)1.0 / r.dx; r.iy = (Real)1.0 / r.dy; r.iz = (Real)1.0 / r.dz;
+    r.sx = r.ix < 0; r.sy = r.iy < 0; r.sz = r.iz < 0;
+}
+
+// aabb.go:62-99.  Returns hit and writes the interval.
+template <typename Real>
+RT_HD bool slab(const Ray<Real> &r, const f4 &lo, const f4 &hi, Real &otmin, Real &otmax) {
+    Real tmin = ((Real)(r.sx ? hi.x : lo.x) - r.ox) * r.ix;
+    Real tmax = ((Real)(r.sx ? lo.x : hi.x) - r.ox) * r.ix;
+    Real tymin = ((Real)(r.sy ? hi.y : lo.y) - r.oy) * r.iy;
+    Real tymax = ((Real)(r.sy ? lo.y : hi.y) - r.oy) * r.iy;
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    Real tzmin = ((Real)(r.sz ? hi.z : lo.z) - r.oz) * r.iz;
+    Real tzmax = ((Real)(r.sz ? lo.z : hi.z) - r.oz) * r.iz;
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    otmin = tmin;
+    otmax = tmax;
+    return true;
+}
+
+template <typename Real>
+struct Hit {
+    Real t, u, v;
+    int32_t pos;
+};
+
+// bvh.go:120-131 for one triangle record: back-face cull, triangle.go:78-103,
+// then "t > 0 && t < tmin" (first visited wins ties).  Returns true when the
+// Moller-Trumbore test was evaluated (for the counters).
+template <typename Real>
+RT_HD bool tri_test(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2, int32_t pos,
+                    Hit<Real> &h) {
+    const Real nx = (Real)q0.x, ny = (Real)q0.y, nz = (Real)q0.z;
+    if (nx * r.dx + ny * r.dy + nz * r.dz > 0) return false;
+    const Real wx = (Real)q2.y, wy = (Real)q2.z, wz = (Real)q2.w;
+    const Real ex = (Real)q1.z, ey = (Real)q1.w, ez = (Real)q2.x;
+    // pvec = D x v0v2
+    const Real px = r.dy * wz - r.dz * wy;
+    const Real py = r.dz * wx - r.dx * wz;
+    const Real pz = r.dx * wy - r.dy * wx;
+    const Real det = ex * px + ey * py + ez * pz;
+    if (det < (Real)0.0001f) return true;
+    const Real invdet = (Real)1.0 / det;
+    const Real tx = r.ox - (Real)q0.w, ty = r.oy - (Real)q1.x, tz = r.oz - (Real)q1.y;
+    const Real u = (tx * px + ty * py + tz * pz) * invdet;
+    if (u < 0 || u > 1) return true;
+    // qvec = tvec x Edge0
+    const Real qx = ty * ez - tz * ey;
+    const Real qy = tz * ex - tx * ez;
+    const Real qz = tx * ey - ty * ex;
+    const Real v = (r.dx * qx + r.dy * qy + r.dz * qz) * invdet;
+    if (v < 0 || u + v > 1) return true;
+    const Real t = (wx * qx + wy * qy + wz * qz) * invdet;
+    if (t > 0 && t < h.t) {
+        h.t = t;
+        h.u = u;
+        h.v = v;
+        h.pos = pos;
+    }
+    return true;
+}
+
+struct Counters {
+    uint32_t nodes_visited = 0, box_tests = 0, tris_fetched = 0, tris_tested = 0;
+};
+
+// One whole reference-order traversal (lane-serial form; the kernels inline the
+// same steps around their wave-level scheduling).  COUNT adds the counters.
+template <typename Real, bool COUNT>
+RT_HD void traverse_ref_order(const DevScene &s, const Ray<Real> &r, Hit<Real> &h, Counters *c) {
+    int32_t node = 0;
+    while (node < s.n_nodes) {
+        const f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
+        const int32_t a = f2i(lo.w), b = f2i(hi.w);
+        bool pass = true;
+        if (node != 0) {   // the root is entered without a box test (trace.go:139)
+            Real t0, t1;
+            if (COUNT) c->box_tests++;
+            pass = slab(r, lo, hi, t0, t1) && t0 < h.t && t1 > 0;
+        }
+        if (b >= 0) {
+            if (pass) {
+                for (int32_t k = 0; k < b; ++k) {
+                    const f4 *q = s.tris + 3 * (size_t)(a + k);
+                    if (COUNT) c->tris_fetched++;
+                    bool tested = tri_test(r, q[0], q[1], q[2], a + k, h);
+                    if (COUNT && tested) c->tris_tested++;
+                }
+            }
+            node = node + 1;
+        } else {
+            if (COUNT && pass) c->nodes_visited++;
+            node = pass ? node + 1 : a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Counter RNG: one splitmix64 stream per camera sample; draw k of a stream is
+// mix(stream + (k+1)*golden).  24-bit floats in [0,1) like Go's rand.Float32.
+// ---------------------------------------------------------------------------
+RT_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
+RT_HD uint64_t rng_stream(int64_t seed, uint64_t path_index) {
+    uint64_t a = mix64((uint64_t)seed + kGolden);
+    return mix64(a ^ (path_index * 0xD1B54A32D192ED03ULL + 0x8CB92BA72F3D8DD7ULL));
+}
+RT_HD uint64_t rng_u64(uint64_t stream, uint32_t counter) {
+    return mix64(stream + ((uint64_t)counter + 1) * kGolden);
+}
+RT_HD float rng_f32(uint64_t stream, uint32_t counter) {
+    return (float)(rng_u64(stream, counter) >> 40) * 0x1p-24f;
+}
+RT_HD uint64_t light_base(uint64_t stream) { return rng_u64(stream ^ 0xA5A5A5A5A5A5A5A5ULL, 0); }
+
+// ---------------------------------------------------------------------------
+// mgl32 float32 vector helpers
+// ---------------------------------------------------------------------------
+struct v3 {
+    float x, y, z;
+};
+RT_HD float dot(const v3 &a, const v3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float lensqr(const v3 &a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_HD float len(const v3 &a) { return (float)sqrt((double)lensqr(a)); }
+RT_HD v3 normalize(const v3 &a) {
+    float l = 1.0f / len(a);
+    return v3{a.x * l, a.y * l, a.z * l};
+}
+RT_HD v3 transform_coordinate(const v3 &v, const float *m) {
+    float t[4];
+    for (int r = 0; r < 4; ++r) t[r] = m[r] * v.x + m[4 + r] * v.y + m[8 + r] * v.z + m[12 + r] * 1.0f;
+    float iw = 1 / t[3];
+    return v3{t[0] * iw, t[1] * iw, t[2] * iw};
+}
+
+// Everything a pass needs on the device, prepared once on the host
+// (context.go:245-275 RenderPass.Initialize, camera.go:43-85).
+struct PassParams {
+    float cam_transform[16];
+    float top_left[3];
+    float steps[2];                 // horizontal, vertical
+    float ppd;
+    int32_t projection;
+    int32_t spp;                    // Camera.RaysPerPixel
+    int32_t x_offset, y_offset, width, height;
+    int64_t rng_seed;
+    int32_t L;                      // LightSampleRays
+    int32_t B;                      // BounceLimit (uint8 range)
+    float light_transform[16];
+    float light_size[2];
+    float light_emission[3];
+    float light_normal[3];
+    int32_t incremental;            // path index = s*pixels + i instead of i*spp + s
+};
+
+// camera.go:99-129
+RT_HD void camera_ray(const DevScene &s, const PassParams &p, int32_t x, int32_t y,
+                      uint64_t path_index, v3 &origin, v3 &dir) {
+    float jx = 0.5f, jy = 0.5f;
+    if (s.n_cam > 0) {
+        uint64_t k = path_index % (uint64_t)s.n_cam;
+        jx = (float)s.cam_tab[2 * k];
+        jy = (float)s.cam_tab[2 * k + 1];
+    }
+    float lx = p.top_left[0] + p.steps[0] * ((float)(p.x_offset + x) + jx);
+    float ly = p.top_left[1] - p.steps[1] * ((float)(p.y_offset + y) + jy);
+    origin = transform_coordinate(v3{lx, ly, -p.ppd}, p.cam_transform);
+    v3 diff;
+    if (p.projection == 0) {
+        diff = v3{origin.x - p.cam_transform[12], origin.y - p.cam_transform[13],
+                  origin.z - p.cam_transform[14]};
+    } else {
+        v3 f = transform_coordinate(v3{0, 0, -1}, p.cam_transform);
+        diff = v3{f.x - p.cam_transform[12], f.y - p.cam_transform[13], f.z - p.cam_transform[14]};
+    }
+    dir = normalize(diff);
+}
+
+// arealight.go:42-56 with the table row chosen by the caller
+RT_HD v3 light_sample(const DevScene &s, const PassParams &p, uint64_t idx, float &pdf) {
+    double a = 0.5, b = 0.5;
+    if (s.n_light > 0) {
+        uint64_t k = idx % (uint64_t)s.n_light;
+        a = s.light_tab[2 * k];
+        b = s.light_tab[2 * k + 1];
+    }
+    v3 sample{(float)(a * 2 - 1) * p.light_size[0], (float)(b * 2 - 1) * p.light_size[1], 0};
+    pdf = 1.0f / (4.0f * p.light_size[0] * p.light_size[1]);
+    return transform_coordinate(sample, p.light_transform);
+}
+
+constexpr int kHemiMaxTries = 64;
+
+// utility.go:50-70 on the counter RNG (bounded number of rejection tries)
+RT_HD v3 random_in_hemisphere(uint64_t stream, uint32_t &ctr, const v3 &normal) {
+    v3 p{0, 0, 0};
+    for (int tries = 0; tries < kHemiMaxTries; ++tries) {
+        p.x = rng_f32(stream, ctr++) * 2 - 1;
+        p.y = rng_f32(stream, ctr++) * 2 - 1;
+        p.z = rng_f32(stream, ctr++) * 2 - 1;
+        if (lensqr(p) < 1) break;
+        if (tries == kHemiMaxTries - 1) p = v3{p.x * 0.5f, p.y * 0.5f, p.z * 0.5f};
+    }
+    if (dot(p, normal) > 0.0f) return p;
+    return v3{p.x * -1, p.y * -1, p.z * -1};
+}
+
+// trace.go:154-187 getMaterialParameters: Kd, optionally times the nearest
+// texel of map_Kd (texture.go:48-59; no V flip, repeat wrap by uv - floor(uv)).
+RT_HD v3 material_diffuse(const DevScene &s, int32_t tri_pos, float u, float v) {
+    const int32_t mat = s.tri_mat[tri_pos] & (kLightBit - 1);
+    v3 kd{s.kd[3 * mat], s.kd[3 * mat + 1], s.kd[3 * mat + 2]};
+    if (s.mat_tex == nullptr || s.tri_uv == nullptr) return kd;
+    const int32_t slot = s.mat_tex[mat];
+    if (slot < 0 || s.tex_data[slot] == nullptr) return kd;
+    const float *tc = s.tri_uv + 6 * (size_t)tri_pos;
+    // TextureCoords[0]*(1-U-V) + TextureCoords[1]*U + TextureCoords[2]*V
+    const float w0 = 1.0f - u - v;
+    float tu = (tc[0] * w0 + tc[2] * u) + tc[4] * v;
+    float tv = (tc[1] * w0 + tc[3] * u) + tc[5] * v;
+    tu = tu - (float)floor((double)tu);
+    tv = tv - (float)floor((double)tv);
+    const int32_t w = s.tex_dim[2 * slot], h = s.tex_dim[2 * slot + 1];
+    int32_t px = (int32_t)(tu * (float)w), py = (int32_t)(tv * (float)h);
+    if (px < 0 || py < 0 || px >= w || py >= h) return v3{0, 0, 0};   // image.RGBA.At outside bounds
+    const uint8_t *t = s.tex_data[slot] + 4 * ((size_t)py * (size_t)w + (size_t)px);
+    // RGBA() widens 8-bit channels to 16 bits (c | c<<8), then * float32(1/65535)
+    const float k = (float)(1.0 / 65535.0);
+    v3 smp{(float)(t[0] * 257) * k, (float)(t[1] * 257) * k, (float)(t[2] * 257) * k};
+    smp = v3{gomath::clamp01(smp.x), gomath::clamp01(smp.y), gomath::clamp01(smp.z)};
+    return v3{kd.x * smp.x, kd.y * smp.y, kd.z * smp.z};
+}
+
+// trace.go:49-71: one light sample at a path vertex.  Returns true when a
+// shadow ray must be cast (lightIncident < 0); colour is what the sample adds
+// to `shading` if that ray reaches the light.
+RT_HD bool shadow_candidate(const DevScene &s, const PassParams &p, const v3 &point,
+                            const v3 &tri_normal, const v3 &diffuse, uint64_t light_idx,
+                            v3 &dir_n, float &dist, v3 &colour) {
+    float pdf;
+    const v3 ls = light_sample(s, p, light_idx, pdf);
+    const v3 sr{ls.x - point.x, ls.y - point.y, ls.z - point.z};
+    dist = len(sr);
+    dir_n = normalize(sr);
+    const v3 ln{p.light_normal[0], p.light_normal[1], p.light_normal[2]};
+    const float li = dot(dir_n, ln);
+    if (!(li < 0)) return false;
+    const float theta_l = (float)gomath::go_max((double)(-li), 0.0);
+    const float theta = (float)gomath::go_max((double)dot(dir_n, tri_normal), 0.0);
+    const float r2 = lensqr(sr);
+    const float pi32 = (float)gomath::kPi;
+    const float k = theta_l * theta / (r2 * pdf * pi32);
+    colour = v3{(diffuse.x * p.light_emission[0]) * k, (diffuse.y * p.light_emission[1]) * k,
+                (diffuse.z * p.light_emission[2]) * k};
+    return true;
+}
+
+// trace.go:100-104: the BRDF factor of a bounce that did hit something
+RT_HD float brdf_factor(const v3 &cur_dir, const v3 &sample, const v3 &normal) {
+    const float brdf_theta = dot(cur_dir, sample) * -1;
+    const float theta = dot(sample, normal);
+    const double pdf = gomath::go_cos((double)brdf_theta) / gomath::kPi;
+    return (float)(gomath::go_cos((double)theta) / (gomath::kPi * pdf));
+}
+
+// main.go:158-182 for one channel
+RT_HD uint8_t resolve_channel(float sum, float inv_divisor, bool gamma_on, double inv_gamma) {
+    float c = sum * inv_divisor;
+    if (gamma_on) c = (float)gomath::go_pow((double)c, inv_gamma);
+    c = gomath::clamp01(c);
+    float x = 255 * c;
+    if (!(x == x)) return 0;
+    if (x <= 0) return 0;
+    if (x >= 255) return 255;
+    return (uint8_t)x;
+}
+
+}  // namespace rtc

@@ -1,0 +1,89 @@
+// rt_device.h -- device-side scene object and the launch entry points the C
+// ABI layer forwards to.  Internal.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <memory>
+#include <vector>
+
+#include "rt_core.h"
+#include "rt_internal.h"
+
+namespace rt {
+
+constexpr uint32_t kCursorSlots = 64;   // ring of ray-queue cursors, one per in-flight launch
+
+// Per-batch path state of the wavefront path tracer (all device pointers).
+struct PathBuffers {
+    rt_ray *rays[2];
+    rt_hit *hits[2];
+    uint32_t *counts;          // queue lengths: [0] primaries, [k+1] rays emitted at vertex k
+    uint8_t *state;
+    uint8_t *n_terms;
+    float *cur_dir;            // P*3
+    uint32_t *rng_ctr;
+    int32_t *bounce_q;
+    int32_t *shadow_q;         // P*L
+    float *shadow_col;         // P*L*3
+    float *shading_terms;      // (B+1)*P*3, vertex-major
+    float *brdf_terms;         // (B+1)*P*3
+    float *radiance;           // P*3, [sample][pixel]
+    unsigned long long *ray_total;
+};
+
+struct Scene {
+    int device = 0;
+    int num_cus = 256;
+    int32_t n_tris = 0, n_nodes = 0, max_depth = 0, n_materials = 0;
+    rt_light light{};
+    // flattened buffers (HBM)
+    rtc::f4 *d_nodes = nullptr;
+    rtc::f4 *d_tris = nullptr;
+    int32_t *d_tri_mat = nullptr;
+    float *d_kd = nullptr;
+    float *d_tri_uv = nullptr;
+    int32_t *d_mat_tex = nullptr;
+    uint8_t **d_tex_ptrs = nullptr;
+    int32_t *d_tex_dims = nullptr;
+    double *d_cam_tab = nullptr;
+    double *d_light_tab = nullptr;
+    int32_t n_cam = 0, n_light = 0;
+    uint32_t *d_cursors = nullptr;
+    std::atomic<uint32_t> cursor_next{0};
+    uint64_t node_bytes = 0, tri_bytes = 0;
+    std::vector<int32_t> mat_tex;
+    std::vector<uint8_t *> tex_ptrs;
+    std::vector<int32_t> tex_dims;
+    // path-tracing workspace (grow-only)
+    size_t max_paths_in_flight = (size_t)1 << 22;
+    size_t ws_paths = 0;
+    int ws_L = 0, ws_B = 0;
+    PathBuffers ws{};
+    std::vector<void *> ws_allocs;
+};
+
+rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **out);
+rt_status scene_set_tables(Scene &sc, const double *cam, int32_t n_cam, const double *lig, int32_t n_lig);
+rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_t w, int32_t h);
+void scene_destroy(Scene *sc);
+
+rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,
+                       rt_hit *d_hits, int mode, unsigned long long *d_counters,
+                       hipStream_t stream);
+rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits, int mode,
+                          bool want_counters, rt_stats *stats);
+rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sample_begin,
+                            int32_t sample_count, bool incremental, bool zero_accum,
+                            float *d_accum, uint8_t *d_rgba, rt_stats *stats, hipStream_t stream);
+rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
+                           uint8_t *rgba, rt_stats *stats);
+rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
+                         float gamma, uint8_t *d_rgba, hipStream_t stream);
+
+}  // namespace rt
+
+struct rt_scene {
+    rt::Scene *impl = nullptr;
+};

@@ -1,0 +1,66 @@
+// rt_internal.h -- host-side data model shared by the builder, the flattener
+// and the C ABI.  Not part of the public interface.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+namespace rt {
+
+constexpr float kF32Max = 3.40282346638528859811704183484516925440e+38f;
+
+// Sets the calling thread's error text and returns `code` (for `return fail(...)`).
+rt_status fail(rt_status code, const std::string &msg);
+
+// Host copy of the BVH in preorder (BVHNode.Index order, bvh.go:59-67).
+struct Bvh {
+    int32_t n_tris = 0;
+    int32_t n_nodes = 0;
+    int32_t max_depth = 0;
+    std::vector<int32_t> is_leaf, start, end, depth;
+    std::vector<float> bmin, bmax, split;   // 3, 3, 4 floats per node
+    std::vector<int32_t> order;             // original triangle id per sorted position
+};
+
+// Validates a mesh description (pointers, counts, finite vertices).
+rt_status check_mesh(const rt_mesh *mesh);
+
+// bvh.go:31-114,146-212
+rt_status build_bvh(const rt_mesh &mesh, bool use_bvh, int32_t max_leaf, int32_t max_depth,
+                    Bvh &out);
+
+// Flat records as the kernels read them (layout: rt_core.h, DevScene).
+struct FlatScene {
+    std::vector<float> nodes;      // n_nodes * 8 floats (2 x 16-byte words)
+    std::vector<float> tris;       // n_tris * 12 floats (3 x 16-byte words)
+    std::vector<int32_t> tri_mat;  // material id | light bit
+    std::vector<float> tri_uv;     // n_tris * 6 or empty
+};
+rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out);
+const std::string &last_error_text();
+
+// Per-triangle precompute of models/triangle.go:45-65 in sorted-array order.
+struct TriRecord {
+    float v0[3], e0[3], v0v2[3], normal[3];
+};
+void make_tri_record(const float v[9], TriRecord &out);
+
+// context.go:172-226 over triangles in sorted-array order.
+void find_light(const rt_mesh &mesh, const std::vector<int32_t> &order, rt_light &out);
+
+// camera.go:43-85
+void camera_setup(const rt_camera &cam, int32_t total_w, int32_t total_h, float top_left[3],
+                  float steps[2]);
+
+// Scrambled Halton (bases 2 and 3) points in [0,1)^2.
+void default_sample_table(int32_t n, uint64_t seed, double *out);
+
+}  // namespace rt
+
+// Opaque handle of the public header.
+struct rt_bvh {
+    rt::Bvh bvh;
+};

@@ -1,0 +1,903 @@
+// rt_kernels.hip -- CDNA4 (gfx950) kernels and their launchers.
+//
+//   k_trace_ref   persistent-wave BVH traversal in the reference's visit order
+//                 (bvh.go:117-144) with the reference's arithmetic
+//                 (aabb.go:62-99, triangle.go:78-103); float32 and float64
+//                 instantiations.  Waves pull rays from a global cursor and
+//                 refill idle lanes (ballot + prefix popcount), so a wave never
+//                 idles on a few long rays.
+//   k_raygen      camera.go:99-129 -> coalesced ray buffer
+//   k_shade       trace.go:44-109 for path vertex k of every live path: folds
+//                 the previous vertex's shadow results, emits this vertex's
+//                 shadow rays and the bounce ray into a compacted queue
+//   k_finish      last vertex's shadows + the back-to-front fold (trace.go:114-118)
+//   k_accumulate  main.go:133-152 pixel sums, in sample order
+//   k_resolve     main.go:158-182
+//
+// There is no matrix work anywhere on this path: every kernel is bound by
+// cache/HBM latency and bandwidth under divergent access, so the design rules
+// are 16-byte loads, compact records, full occupancy and wave-level queueing.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_core.h"
+#include "rt_device.h"
+#include "rt_internal.h"
+
+using namespace rtc;
+
+namespace rt {
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// wave helpers (wave64)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Wave-aggregated queue append: one atomic per wave, slots in lane order.
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & lanemask_lt());
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Traversal, reference order.  One lane = one ray; the wave is persistent.
+// ---------------------------------------------------------------------------
+constexpr int kRefillBelow = 40;   // refill idle lanes once fewer are active
+
+template <typename Real, bool COUNT>
+__global__ void __launch_bounds__(256)
+k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
+            uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
+            unsigned long long *counters) {
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    int32_t idx = -1;            // ray owned by this lane, -1 = idle
+    bool exhausted = false;      // wave-uniform: the cursor has passed n
+    Ray<Real> r;
+    Hit<Real> h;
+    int32_t node = 0, leaf_a = 0, leaf_n = 0;
+    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
+
+    for (;;) {
+        uint64_t active = __ballot(idx >= 0);
+        if (!exhausted && __popcll(active) < kRefillBelow) {
+            const uint64_t idle = ~active;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const int leader = __ffsll((unsigned long long)idle) - 1;
+            uint32_t base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(next, n_idle);
+            base = __shfl(base, leader);
+            if (idx < 0) {
+                const uint32_t mine = base + (uint32_t)__popcll(idle & lanemask_lt());
+                if (mine < n) {
+                    const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
+                    const f4 a = rp[0], b = rp[1];
+                    ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
+                    h.t = (Real)a.w;
+                    h.u = 0;
+                    h.v = 0;
+                    h.pos = -1;
+                    node = 0;
+                    leaf_n = 0;
+                    idx = (int32_t)mine;
+                }
+            }
+            if (base + n_idle >= n || base + n_idle < base) exhausted = true;
+            active = __ballot(idx >= 0);
+        }
+        if (active == 0) break;
+
+        // phase A: walk boxes until this lane stands on a passed leaf
+        while (idx >= 0 && node < s.n_nodes && leaf_n == 0) {
+            const f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
+            const int32_t a = f2i(lo.w), b = f2i(hi.w);
+            bool pass = true;
+            if (node != 0) {
+                Real t0, t1;
+                if (COUNT) c_box++;
+                pass = slab(r, lo, hi, t0, t1) && t0 < h.t && t1 > 0;
+            }
+            if (b >= 0) {
+                if (pass) {
+                    leaf_a = a;
+                    leaf_n = b;
+                }
+                node = node + 1;
+            } else {
+                if (COUNT && pass) c_nodes++;
+                node = pass ? node + 1 : a;
+            }
+        }
+        // phase B: the leaf's triangles, in array order
+        if (idx >= 0 && leaf_n > 0) {
+            for (int32_t k = 0; k < leaf_n; ++k) {
+                const f4 *q = s.tris + 3 * (size_t)(leaf_a + k);
+                const f4 q0 = q[0], q1 = q[1], q2 = q[2];
+                if (COUNT) c_fetch++;
+                const bool tested = tri_test(r, q0, q1, q2, leaf_a + k, h);
+                if (COUNT && tested) c_test++;
+            }
+            leaf_n = 0;
+        }
+        if (idx >= 0 && node >= s.n_nodes) {
+            f4 out;
+            out.x = i2f(h.pos);
+            out.y = (float)h.t;
+            out.z = (float)h.u;
+            out.w = (float)h.v;
+            *reinterpret_cast<f4 *>(hits + idx) = out;
+            idx = -1;
+        }
+    }
+    if (COUNT) {
+        c_nodes = wave_sum(c_nodes);
+        c_box = wave_sum(c_box);
+        c_fetch = wave_sum(c_fetch);
+        c_test = wave_sum(c_test);
+        if (lane_id() == 0) {
+            atomicAdd(counters + 1, (unsigned long long)c_nodes);
+            atomicAdd(counters + 2, (unsigned long long)c_box);
+            atomicAdd(counters + 3, (unsigned long long)c_fetch);
+            atomicAdd(counters + 4, (unsigned long long)c_test);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + 0, (unsigned long long)n);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Path-tracing wavefront kernels
+// ---------------------------------------------------------------------------
+enum : uint8_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
+
+struct Batch {
+    uint32_t P;                // paths in this batch = n_pix * n_samp
+    uint32_t n_pix;            // pixels in this batch
+    uint32_t pix0;             // first pixel (tile-linear)
+    uint32_t s0;               // first sample index
+    uint32_t n_samp;
+};
+
+__device__ __forceinline__ uint64_t path_index_of(const PassParams &p, uint32_t pix, uint32_t s) {
+    const uint64_t pixels = (uint64_t)p.width * (uint64_t)p.height;
+    return p.incremental ? (uint64_t)s * pixels + pix : (uint64_t)pix * (uint64_t)p.spp + s;
+}
+
+__global__ void __launch_bounds__(256)
+k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id == 0) w.counts[0] = b.P;
+    if (id >= b.P) return;
+    const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
+    const uint32_t pix = b.pix0 + pl, smp = b.s0 + sl;
+    const int32_t x = (int32_t)(pix % (uint32_t)p.width), y = (int32_t)(pix / (uint32_t)p.width);
+    v3 o, d;
+    camera_ray(s, p, x, y, path_index_of(p, pix, smp), o, d);
+    f4 *rp = reinterpret_cast<f4 *>(w.rays[0] + id);
+    rp[0] = f4{o.x, o.y, o.z, kF32Max};
+    rp[1] = f4{d.x, d.y, d.z, 0.0f};
+    w.state[id] = kActive;
+    w.n_terms[id] = 0;
+    w.rng_ctr[id] = 0;
+    w.cur_dir[3 * (size_t)id + 0] = d.x;
+    w.cur_dir[3 * (size_t)id + 1] = d.y;
+    w.cur_dir[3 * (size_t)id + 2] = d.z;
+}
+
+// Sum of the shadow samples that reached the light, scaled and clamped
+// (trace.go:63-77).  `in` is the queue the shadow rays of the previous vertex
+// were traced in.
+__device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &p,
+                                           const PathBuffers &w, int in, uint32_t id) {
+    v3 shading{0, 0, 0};
+    for (int i = 0; i < p.L; ++i) {
+        const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
+        const int32_t q = w.shadow_q[slot];
+        if (q < 0) continue;
+        const float dist = w.rays[in][q].tmax;
+        const rt_hit sh = w.hits[in][q];
+        const bool reached = sh.t < kF32Max;   // rayCast returned a result
+        const bool lit = reached && (sh.t >= dist ||
+                                     (sh.tri_pos >= 0 && (s.tri_mat[sh.tri_pos] & kLightBit) != 0));
+        if (lit) {
+            shading.x = shading.x + w.shadow_col[3 * slot + 0];
+            shading.y = shading.y + w.shadow_col[3 * slot + 1];
+            shading.z = shading.z + w.shadow_col[3 * slot + 2];
+        }
+    }
+    const float invl = 1 / (float)p.L;
+    return v3{gomath::clamp01(shading.x * invl), gomath::clamp01(shading.y * invl),
+              gomath::clamp01(shading.z * invl)};
+}
+
+__device__ __forceinline__ void store3(float *base, size_t i, const v3 &v) {
+    base[3 * i + 0] = v.x;
+    base[3 * i + 1] = v.y;
+    base[3 * i + 2] = v.z;
+}
+
+// Path vertex k.  Reads queue (k & 1), writes queue ((k+1) & 1).
+__global__ void __launch_bounds__(256)
+k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = id < b.P && w.state[id] == kActive;
+    const int in = k & 1, out = in ^ 1;
+    uint32_t *out_count = w.counts + k + 1;
+    const size_t P = b.P;
+
+    bool at_vertex = false;
+    rt_hit hit{};
+    v3 ro{0, 0, 0}, rd{0, 0, 0};
+    if (live) {
+        uint32_t q = id;
+        if (k > 0) {
+            const v3 sh = fold_shadows(s, p, w, in, id);
+            store3(w.shading_terms, (size_t)(k - 1) * P + id, sh);
+            q = (uint32_t)w.bounce_q[id];
+        }
+        hit = w.hits[in][q];
+        if (!(hit.t < kF32Max)) {
+            // primary miss: Trace returns the background; bounce miss: BRDF term 0
+            if (k > 0) store3(w.brdf_terms, (size_t)(k - 1) * P + id, v3{0, 0, 0});
+            w.n_terms[id] = (uint8_t)k;
+            w.state[id] = kComplete;
+        } else {
+            const f4 *rp = reinterpret_cast<const f4 *>(w.rays[in] + q);
+            const f4 a = rp[0], c = rp[1];
+            ro = v3{a.x, a.y, a.z};
+            rd = v3{c.x, c.y, c.z};
+            at_vertex = true;
+        }
+    }
+
+    v3 point{0, 0, 0}, normal{0, 0, 1}, diffuse{0, 0, 0};
+    if (at_vertex) {
+        point = v3{ro.x + rd.x * hit.t, ro.y + rd.y * hit.t, ro.z + rd.z * hit.t};
+        const f4 q0 = s.tris[3 * (size_t)hit.tri_pos];
+        normal = v3{q0.x, q0.y, q0.z};
+        diffuse = material_diffuse(s, hit.tri_pos, hit.u, hit.v);
+    }
+    const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
+    const uint64_t stream = rng_stream(p.rng_seed, path_index_of(p, b.pix0 + pl, b.s0 + sl));
+    const uint64_t lbase = light_base(stream);
+
+    // shadow rays of this vertex (the loop is uniform over the wave: L is a pass constant)
+    for (int i = 0; i < p.L; ++i) {
+        v3 dn{0, 0, 0}, col{0, 0, 0};
+        float dist = 0;
+        bool cast = false;
+        if (at_vertex)
+            cast = shadow_candidate(s, p, point, normal, diffuse,
+                                    lbase + (uint64_t)k * (uint64_t)p.L + (uint64_t)i, dn, dist, col);
+        const uint32_t q = wave_append(out_count, cast);
+        if (at_vertex) {
+            const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
+            if (cast) {
+                f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + q);
+                rp[0] = f4{point.x, point.y, point.z, dist};
+                rp[1] = f4{dn.x, dn.y, dn.z, 0.0f};
+                w.shadow_q[slot] = (int32_t)q;
+                store3(w.shadow_col, slot, col);
+            } else {
+                w.shadow_q[slot] = -1;
+            }
+        }
+    }
+
+    // bounce (trace.go:81-108)
+    bool bounce = false;
+    v3 sample{0, 0, 0};
+    if (at_vertex) {
+        if (k >= p.B) {
+            store3(w.brdf_terms, (size_t)k * P + id, v3{0, 0, 0});
+            w.n_terms[id] = (uint8_t)(k + 1);
+            w.state[id] = kLastVertex;
+        } else {
+            uint32_t ctr = w.rng_ctr[id];
+            sample = normalize(random_in_hemisphere(stream, ctr, normal));
+            w.rng_ctr[id] = ctr;
+            bounce = true;
+        }
+    }
+    const uint32_t bq = wave_append(out_count, bounce);
+    if (bounce) {
+        f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + bq);
+        rp[0] = f4{point.x, point.y, point.z, kF32Max};
+        rp[1] = f4{sample.x, sample.y, sample.z, 0.0f};
+        w.bounce_q[id] = (int32_t)bq;
+        const v3 cur{w.cur_dir[3 * (size_t)id], w.cur_dir[3 * (size_t)id + 1], w.cur_dir[3 * (size_t)id + 2]};
+        const float f = brdf_factor(cur, sample, normal);
+        // provisional: zeroed by the next vertex if the bounce ray hits nothing
+        store3(w.brdf_terms, (size_t)k * P + id, v3{diffuse.x * f, diffuse.y * f, diffuse.z * f});
+        store3(w.cur_dir, id, sample);
+    }
+}
+
+// Last vertex's shadows, then E = shading[0] + brdf[0] folded back to front.
+__global__ void __launch_bounds__(256)
+k_finish(DevScene s, PassParams p, Batch b, PathBuffers w, int last_queue) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= b.P) return;
+    const size_t P = b.P;
+    uint8_t st = w.state[id];
+    const int n = w.n_terms[id];
+    if (st == kLastVertex) {
+        const v3 sh = fold_shadows(s, p, w, last_queue, id);
+        store3(w.shading_terms, (size_t)(n - 1) * P + id, sh);
+    }
+    v3 rgb{0.0f / 255.0f, 0.0f / 255.0f, 0.0f / 255.0f};
+    if (n > 0) {
+        size_t i = (size_t)(n - 1) * P + id;
+        v3 x{w.brdf_terms[3 * i], w.brdf_terms[3 * i + 1], w.brdf_terms[3 * i + 2]};
+        for (int t = n - 2; t >= 0; --t) {
+            const size_t hi = (size_t)(t + 1) * P + id, lo = (size_t)t * P + id;
+            const v3 sn{w.shading_terms[3 * hi], w.shading_terms[3 * hi + 1], w.shading_terms[3 * hi + 2]};
+            const v3 bt{w.brdf_terms[3 * lo], w.brdf_terms[3 * lo + 1], w.brdf_terms[3 * lo + 2]};
+            x = v3{bt.x * (sn.x + x.x), bt.y * (sn.y + x.y), bt.z * (sn.z + x.z)};
+        }
+        rgb = v3{w.shading_terms[3 * (size_t)id] + x.x, w.shading_terms[3 * (size_t)id + 1] + x.y,
+                 w.shading_terms[3 * (size_t)id + 2] + x.z};
+    }
+    store3(w.radiance, id, rgb);
+    w.state[id] = kDone;
+}
+
+// pixelColor += rayColor, samples in order (main.go:137-151)
+__global__ void __launch_bounds__(256)
+k_accumulate(Batch b, const float *__restrict__ radiance, float *__restrict__ accum) {
+    const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl >= b.n_pix) return;
+    const size_t pix = (size_t)b.pix0 + pl;
+    float r = accum[3 * pix], g = accum[3 * pix + 1], bl = accum[3 * pix + 2];
+    for (uint32_t sidx = 0; sidx < b.n_samp; ++sidx) {
+        const size_t i = (size_t)sidx * b.n_pix + pl;
+        r = r + radiance[3 * i];
+        g = g + radiance[3 * i + 1];
+        bl = bl + radiance[3 * i + 2];
+    }
+    accum[3 * pix] = r;
+    accum[3 * pix + 1] = g;
+    accum[3 * pix + 2] = bl;
+}
+
+__global__ void __launch_bounds__(256)
+k_resolve(const float *__restrict__ accum, size_t pixels, float inv_divisor, int gamma_on,
+          double inv_gamma, uint8_t *__restrict__ rgba) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels) return;
+    uchar4 o;
+    o.x = resolve_channel(accum[3 * i], inv_divisor, gamma_on != 0, inv_gamma);
+    o.y = resolve_channel(accum[3 * i + 1], inv_divisor, gamma_on != 0, inv_gamma);
+    o.z = resolve_channel(accum[3 * i + 2], inv_divisor, gamma_on != 0, inv_gamma);
+    o.w = 255;
+    reinterpret_cast<uchar4 *>(rgba)[i] = o;
+}
+
+__global__ void k_sum_counts(const uint32_t *counts, int n, unsigned long long *total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < n; ++i) t += counts[i];
+        *total += t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Device scene
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+rt_status upload(T **dst, const void *src, size_t bytes) {
+    *dst = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) ok = false;
+        if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(RT_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(RT_ERR_INVALID, "device index " + std::to_string(device) + " out of range");
+    if (bvh.n_tris != mesh.n_tris)
+        return fail(RT_ERR_INVALID, "BVH was built for a different triangle count");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+
+    std::unique_ptr<Scene> sc(new Scene);
+    sc->device = device;
+    sc->n_tris = mesh.n_tris;
+    sc->n_nodes = bvh.n_nodes;
+    sc->max_depth = bvh.max_depth;
+    sc->n_materials = mesh.n_materials;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    sc->num_cus = prop.multiProcessorCount;
+
+    FlatScene flat;
+    rt_status st = flatten(mesh, bvh, flat);
+    if (st != RT_OK) return st;
+    find_light(mesh, bvh.order, sc->light);
+
+    if ((st = upload(&sc->d_nodes, flat.nodes.data(), flat.nodes.size() * 4)) != RT_OK) return st;
+    if ((st = upload(&sc->d_tris, flat.tris.data(), flat.tris.size() * 4)) != RT_OK) return st;
+    if ((st = upload(&sc->d_tri_mat, flat.tri_mat.data(), flat.tri_mat.size() * 4)) != RT_OK) return st;
+    if ((st = upload(&sc->d_kd, mesh.kd, (size_t)mesh.n_materials * 12)) != RT_OK) return st;
+    if (mesh.texcoords)
+        if ((st = upload(&sc->d_tri_uv, flat.tri_uv.data(), flat.tri_uv.size() * 4)) != RT_OK) return st;
+    sc->mat_tex.assign((size_t)mesh.n_materials, -1);
+    if (mesh.texture)
+        for (int32_t m = 0; m < mesh.n_materials; ++m) sc->mat_tex[(size_t)m] = mesh.texture[m];
+    if ((st = upload(&sc->d_mat_tex, sc->mat_tex.data(), sc->mat_tex.size() * 4)) != RT_OK) return st;
+    sc->node_bytes = flat.nodes.size() * 4;
+    sc->tri_bytes = flat.tris.size() * 4;
+    if ((st = upload(&sc->d_cursors, nullptr, kCursorSlots * sizeof(uint32_t))) != RT_OK) return st;
+    HIP_TRY(hipMemset(sc->d_cursors, 0, kCursorSlots * sizeof(uint32_t)));
+
+    // default sample tables (same row counts as the reference's)
+    std::vector<double> cam((size_t)12345 * 2), lig((size_t)100001 * 2);
+    default_sample_table(12345, 0xC0FFEE01ULL, cam.data());
+    default_sample_table(100001, 0xC0FFEE02ULL, lig.data());
+    if ((st = scene_set_tables(*sc, cam.data(), 12345, lig.data(), 100001)) != RT_OK) return st;
+    *out = sc.release();
+    return RT_OK;
+}
+
+rt_status scene_set_tables(Scene &sc, const double *cam, int32_t n_cam, const double *lig,
+                           int32_t n_lig) {
+    if (n_cam < 0 || n_lig < 0 || (n_cam > 0 && !cam) || (n_lig > 0 && !lig))
+        return fail(RT_ERR_INVALID, "bad sample table arguments");
+    DeviceGuard guard(sc.device);
+    if (sc.d_cam_tab) (void)hipFree(sc.d_cam_tab);
+    if (sc.d_light_tab) (void)hipFree(sc.d_light_tab);
+    sc.d_cam_tab = sc.d_light_tab = nullptr;
+    rt_status st;
+    if ((st = upload(&sc.d_cam_tab, cam, (size_t)n_cam * 16)) != RT_OK) return st;
+    if ((st = upload(&sc.d_light_tab, lig, (size_t)n_lig * 16)) != RT_OK) return st;
+    sc.n_cam = n_cam;
+    sc.n_light = n_lig;
+    return RT_OK;
+}
+
+rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_t w, int32_t h) {
+    if (slot < 0 || slot >= 4096 || !rgba || w <= 0 || h <= 0)
+        return fail(RT_ERR_INVALID, "bad texture arguments");
+    DeviceGuard guard(sc.device);
+    if ((size_t)slot >= sc.tex_ptrs.size()) {
+        sc.tex_ptrs.resize((size_t)slot + 1, nullptr);
+        sc.tex_dims.resize(2 * ((size_t)slot + 1), 0);
+    }
+    if (sc.tex_ptrs[(size_t)slot]) (void)hipFree(sc.tex_ptrs[(size_t)slot]);
+    uint8_t *d = nullptr;
+    rt_status st;
+    if ((st = upload(&d, rgba, (size_t)w * (size_t)h * 4)) != RT_OK) return st;
+    sc.tex_ptrs[(size_t)slot] = d;
+    sc.tex_dims[2 * (size_t)slot] = w;
+    sc.tex_dims[2 * (size_t)slot + 1] = h;
+    if (sc.d_tex_ptrs) (void)hipFree(sc.d_tex_ptrs);
+    if (sc.d_tex_dims) (void)hipFree(sc.d_tex_dims);
+    if ((st = upload(&sc.d_tex_ptrs, sc.tex_ptrs.data(), sc.tex_ptrs.size() * sizeof(uint8_t *))) != RT_OK) return st;
+    if ((st = upload(&sc.d_tex_dims, sc.tex_dims.data(), sc.tex_dims.size() * 4)) != RT_OK) return st;
+    return RT_OK;
+}
+
+void workspace_free(Scene &sc) {
+    for (void *p : sc.ws_allocs) (void)hipFree(p);
+    sc.ws_allocs.clear();
+    sc.ws_paths = 0;
+}
+
+void scene_destroy(Scene *sc) {
+    if (!sc) return;
+    DeviceGuard guard(sc->device);
+    workspace_free(*sc);
+    for (uint8_t *p : sc->tex_ptrs)
+        if (p) (void)hipFree(p);
+    void *ptrs[] = {sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+                    sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete sc;
+}
+
+static DevScene dev_view(const Scene &sc) {
+    DevScene d{};
+    d.nodes = sc.d_nodes;
+    d.tris = sc.d_tris;
+    d.tri_mat = sc.d_tri_mat;
+    d.kd = sc.d_kd;
+    d.tri_uv = sc.d_tri_uv;
+    d.mat_tex = sc.d_tex_ptrs ? sc.d_mat_tex : nullptr;
+    d.tex_data = sc.d_tex_ptrs;
+    d.tex_dim = sc.d_tex_dims;
+    d.cam_tab = sc.d_cam_tab;
+    d.light_tab = sc.d_light_tab;
+    d.n_nodes = sc.n_nodes;
+    d.n_tris = sc.n_tris;
+    d.n_cam = sc.n_cam;
+    d.n_light = sc.n_light;
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+
+// Persistent grid: enough 256-thread blocks to fill every CU at the kernel's
+// occupancy, never more blocks than there are 64-ray chunks.
+static uint32_t trace_grid(const Scene &sc, size_t n) {
+    const size_t chunks = (n + 255) / 256;
+    size_t blocks = (size_t)sc.num_cus * 8;
+    if (blocks > chunks) blocks = chunks;
+    if (blocks == 0) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+static uint32_t *next_cursor(Scene &sc) {
+    const uint32_t slot = sc.cursor_next.fetch_add(1) % kCursorSlots;
+    return sc.d_cursors + slot;
+}
+
+rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,
+                       rt_hit *d_hits, int mode, unsigned long long *d_counters,
+                       hipStream_t stream) {
+    if (n_host == 0) return RT_OK;
+    if (n_host > 0x7fffffffULL) return fail(RT_ERR_INVALID, "more than 2^31-1 rays in one call");
+    uint32_t *cursor = next_cursor(sc);
+    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
+    const DevScene d = dev_view(sc);
+    const dim3 grid(trace_grid(sc, n_host)), block(256);
+    const uint32_t n32 = (uint32_t)n_host;
+    switch (mode) {
+    case RT_MODE_STRICT_F32:
+    case RT_MODE_FAST_F32:   // no reordered kernel yet: the fast mode runs the reference order
+        if (d_counters)
+            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+        else
+            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+        break;
+    case RT_MODE_FP64:
+        if (d_counters)
+            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+        else
+            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+        break;
+    default:
+        return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits, int mode,
+                          bool want_counters, rt_stats *stats) {
+    DeviceGuard guard(sc.device);
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    if (!rays || !hits) return fail(RT_ERR_INVALID, "rays/hits is NULL");
+    rt_ray *d_rays = nullptr;
+    rt_hit *d_hits = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    rt_status st = RT_OK;
+    auto cleanup = [&]() {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_hits) (void)hipFree(d_hits);
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define TRY_CLEAN(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            cleanup();                                                                    \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        }                                                                                 \
+    } while (0)
+    TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_rays), n * sizeof(rt_ray)));
+    TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_hits), n * sizeof(rt_hit)));
+    TRY_CLEAN(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    if (want_counters) {
+        TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_cnt), 5 * sizeof(unsigned long long)));
+        TRY_CLEAN(hipMemset(d_cnt, 0, 5 * sizeof(unsigned long long)));
+    }
+    TRY_CLEAN(hipEventCreate(&e0));
+    TRY_CLEAN(hipEventCreate(&e1));
+    TRY_CLEAN(hipEventRecord(e0, nullptr));
+    st = launch_trace(sc, d_rays, n, nullptr, d_hits, mode, d_cnt, nullptr);
+    if (st != RT_OK) {
+        cleanup();
+        return st;
+    }
+    TRY_CLEAN(hipEventRecord(e1, nullptr));
+    TRY_CLEAN(hipEventSynchronize(e1));
+    TRY_CLEAN(hipMemcpy(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    if (stats) {
+        float ms = 0;
+        TRY_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+        stats->kernel_ms = ms;
+        stats->total_ms = ms;
+        stats->rays = n;
+        if (want_counters) {
+            unsigned long long c[5];
+            TRY_CLEAN(hipMemcpy(c, d_cnt, sizeof c, hipMemcpyDeviceToHost));
+            stats->nodes_visited = c[1];
+            stats->box_tests = c[2];
+            stats->tris_fetched = c[3];
+            stats->tris_tested = c[4];
+        }
+    }
+#undef TRY_CLEAN
+    cleanup();
+    return RT_OK;
+}
+
+// context.go:245-275 (RenderPass.Initialize) + camera.go:43-85, on the host
+static rt_status prepare_pass(const Scene &sc, const rt_pass &pass, PassParams &pp) {
+    std::memset(&pp, 0, sizeof pp);
+    if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
+    if (pass.camera.rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "Camera.RaysPerPixel must be positive");
+    if (pass.settings.light_sample_rays < 0) return fail(RT_ERR_INVALID, "LightSampleRays is negative");
+    rt_camera cam = pass.camera;
+    const float tr = cam.transform[0] + cam.transform[5] + cam.transform[10] + cam.transform[15];
+    if (std::fabs((double)tr) < 0.001) {
+        std::memset(cam.transform, 0, sizeof cam.transform);
+        cam.transform[0] = cam.transform[5] = cam.transform[10] = cam.transform[15] = 1;
+    }
+    std::memcpy(pp.cam_transform, cam.transform, sizeof pp.cam_transform);
+    const int32_t tw = pass.total_width < 0 ? 0 : pass.total_width;
+    const int32_t th = pass.total_height < 0 ? 0 : pass.total_height;
+    camera_setup(cam, tw, th, pp.top_left, pp.steps);
+    pp.ppd = cam.projection_plane_distance;
+    pp.projection = cam.projection;
+    pp.spp = cam.rays_per_pixel;
+    pp.x_offset = pass.x_offset;
+    pp.y_offset = pass.y_offset;
+    pp.width = pass.width;
+    pp.height = pass.height;
+    pp.rng_seed = pass.rng_seed;
+    pp.L = pass.settings.light_sample_rays;
+    pp.B = pass.settings.bounce_limit & 0xff;
+    rt_light light = sc.light;
+    const rt_settings &st = pass.settings;
+    if (!light.found || st.force_debug_light) {
+        const float *m = st.debug_light_at_camera ? cam.transform : st.debug_light_transform;
+        std::memcpy(light.transform, m, sizeof light.transform);
+        const v3 f = transform_coordinate(v3{0, 0, -1}, m);
+        light.normal[0] = f.x - m[12];
+        light.normal[1] = f.y - m[13];
+        light.normal[2] = f.z - m[14];
+        light.size[0] = light.size[1] = st.debug_light_size;
+    }
+    for (int k = 0; k < 3; ++k) light.emission[k] = 1.0f * st.light_intensity;
+    std::memcpy(pp.light_transform, light.transform, sizeof pp.light_transform);
+    std::memcpy(pp.light_size, light.size, sizeof pp.light_size);
+    std::memcpy(pp.light_emission, light.emission, sizeof pp.light_emission);
+    std::memcpy(pp.light_normal, light.normal, sizeof pp.light_normal);
+    return RT_OK;
+}
+
+// Grow-only workspace for `paths` simultaneous paths with L light samples and
+// B bounces; every buffer is reused across batches and calls.
+static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuffers &w) {
+    const size_t Lc = (size_t)(L > 0 ? L : 1);
+    if (sc.ws_paths < paths || sc.ws_L < L || sc.ws_B < B) {
+        workspace_free(sc);
+        const size_t P = paths, qcap = P * (Lc + 1);
+        auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+            if (e == hipSuccess) sc.ws_allocs.push_back(*p);
+            return e;
+        };
+        PathBuffers &b = sc.ws;
+        std::memset(&b, 0, sizeof b);
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(alloc(reinterpret_cast<void **>(&b.rays[i]), qcap * sizeof(rt_ray)));
+            HIP_TRY(alloc(reinterpret_cast<void **>(&b.hits[i]), qcap * sizeof(rt_hit)));
+        }
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.counts), (size_t)(B + 3) * sizeof(uint32_t) + 256));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.state), P));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.cur_dir), P * 12));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shading_terms), P * (size_t)(B + 1) * 12));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.radiance), P * 12));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.ray_total), 64));
+        sc.ws_paths = paths;
+        sc.ws_L = L;
+        sc.ws_B = B;
+    }
+    w = sc.ws;
+    return RT_OK;
+}
+
+rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sample_begin,
+                            int32_t sample_count, bool incremental, bool zero_accum,
+                            float *d_accum, uint8_t *d_rgba, rt_stats *stats,
+                            hipStream_t stream) {
+    DeviceGuard guard(sc.device);
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (!d_accum) return fail(RT_ERR_INVALID, "accumulation buffer is NULL");
+    if (sample_begin < 0 || sample_count < 0) return fail(RT_ERR_INVALID, "bad sample range");
+    if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64)
+        return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
+    PassParams pp;
+    rt_status st = prepare_pass(sc, pass, pp);
+    if (st != RT_OK) return st;
+    pp.incremental = incremental ? 1 : 0;
+    const size_t pixels = (size_t)pass.width * (size_t)pass.height;
+    const int L = pp.L, B = pp.B;
+
+    // batch shape: whole pixel rows of the tile-linear range x as many samples as fit
+    const size_t max_paths = sc.max_paths_in_flight;
+    size_t n_pix = pixels < max_paths ? pixels : max_paths;
+    size_t n_samp = max_paths / n_pix;
+    if (n_samp < 1) n_samp = 1;
+    if (n_samp > (size_t)sample_count) n_samp = (size_t)(sample_count > 0 ? sample_count : 1);
+    PathBuffers w;
+    st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
+    if (st != RT_OK) return st;
+
+    const DevScene d = dev_view(sc);
+    if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    auto timed_trace = [&](const rt_ray *rays, size_t cap, const uint32_t *cnt, rt_hit *hits) -> rt_status {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (stats) {
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            trace_events.emplace_back(a, b);
+            HIP_TRY(hipEventRecord(a, stream));
+        }
+        rt_status s2 = launch_trace(sc, rays, cap, cnt, hits, mode, nullptr, stream);
+        if (s2 != RT_OK) return s2;
+        if (stats) HIP_TRY(hipEventRecord(b, stream));
+        return RT_OK;
+    };
+
+    for (size_t pix0 = 0; pix0 < pixels; pix0 += n_pix) {
+        const size_t np = (pixels - pix0) < n_pix ? (pixels - pix0) : n_pix;
+        for (size_t s0 = 0; s0 < (size_t)sample_count; s0 += n_samp) {
+            const size_t ns = ((size_t)sample_count - s0) < n_samp ? ((size_t)sample_count - s0) : n_samp;
+            Batch b;
+            b.P = (uint32_t)(np * ns);
+            b.n_pix = (uint32_t)np;
+            b.pix0 = (uint32_t)pix0;
+            b.s0 = (uint32_t)(sample_begin + (int32_t)s0);
+            b.n_samp = (uint32_t)ns;
+            const dim3 block(256), grid((b.P + 255) / 256);
+            const size_t qcap = (size_t)b.P * (size_t)((L > 0 ? L : 1) + 1);
+            HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)(B + 3) * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, d, pp, b, w);
+            if ((st = timed_trace(w.rays[0], b.P, w.counts + 0, w.hits[0])) != RT_OK) return st;
+            for (int k = 0; k <= B; ++k) {
+                hipLaunchKernelGGL(k_shade, grid, block, 0, stream, d, pp, b, w, k);
+                const int o = (k + 1) & 1;
+                if ((st = timed_trace(w.rays[o], qcap, w.counts + k + 1, w.hits[o])) != RT_OK) return st;
+            }
+            hipLaunchKernelGGL(k_finish, grid, block, 0, stream, d, pp, b, w, (B + 1) & 1);
+            hipLaunchKernelGGL(k_accumulate, dim3((b.n_pix + 255) / 256), block, 0, stream, b, w.radiance, d_accum);
+            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, w.counts, B + 2, w.ray_total);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (d_rgba) {
+        const int32_t divisor = sample_begin + sample_count;
+        const float inv = 1.0f / (float)divisor;
+        const double inv_gamma = (double)(1.0f / pass.settings.gamma);
+        hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream,
+                           d_accum, pixels, inv, pass.settings.gamma_correction, inv_gamma, d_rgba);
+        HIP_TRY(hipGetLastError());
+    }
+    if (stats) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        stats->total_ms = ms;
+        double kms = 0;
+        for (auto &pr : trace_events) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+            kms += t;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        stats->kernel_ms = kms;
+        unsigned long long total = 0;
+        HIP_TRY(hipMemcpy(&total, w.ray_total, 8, hipMemcpyDeviceToHost));
+        stats->rays = total;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return RT_OK;
+}
+
+rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
+                         float gamma, uint8_t *d_rgba, hipStream_t stream) {
+    if (!d_accum || !d_rgba) return fail(RT_ERR_INVALID, "resolve buffers are NULL");
+    if (pixels == 0) return RT_OK;
+    const float inv = 1.0f / (float)divisor;
+    const double inv_gamma = (double)(1.0f / gamma);
+    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream,
+                       d_accum, pixels, inv, gamma_on, inv_gamma, d_rgba);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
+                           uint8_t *rgba, rt_stats *stats) {
+    DeviceGuard guard(sc.device);
+    if (!rgba) return fail(RT_ERR_INVALID, "rgba is NULL");
+    if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
+    const size_t pixels = (size_t)pass.width * (size_t)pass.height;
+    float *d_accum = nullptr;
+    uint8_t *d_rgba = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_accum), pixels * 12));
+    if (hipMalloc(reinterpret_cast<void **>(&d_rgba), pixels * 4) != hipSuccess) {
+        (void)hipFree(d_accum);
+        return fail(RT_ERR_NOMEM, "hipMalloc of the tile image failed");
+    }
+    rt_stats local;
+    rt_status st = render_accumulate(sc, pass, mode, 0, pass.camera.rays_per_pixel, false, true,
+                                     d_accum, d_rgba, stats ? stats : &local, nullptr);
+    if (st == RT_OK) {
+        hipError_t e = hipMemcpy(rgba, d_rgba, pixels * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && accum_rgb) e = hipMemcpy(accum_rgb, d_accum, pixels * 12, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(RT_ERR_DEVICE, std::string("copy-back failed: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_accum);
+    (void)hipFree(d_rgba);
+    return st;
+}
+
+}  // namespace rt
