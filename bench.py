@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mrays/s (primary + shadow + bounce rays, every
+rayCast of the reference counts, process/trace.go:122) for one tiled
+path-traced frame of the synthetic 1M-triangle room.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one whole 3840x2160 frame at --spp samples per pixel, 4 diffuse
+bounces, 1 light sample per vertex, cut into the frontend's 16x16 tile grid
+(Renderer.js:388-405).  Tiles are dealt block-cyclically to the N ranks (one
+process per GPU), every rank renders its tiles with the scene replicated in its
+HBM, the RGBA8 tiles are gathered to rank 0 over RCCL and the ray counters are
+all-reduced.  The frame is fixed, so scaling is strong.
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      achieved algorithmic bytes/s of the traversal kernel against
+                the HBM peak (bytes per ray from traversal counters measured on
+                a sample tile before the timed region)
+  cpu_baseline  the CPU oracle (a scalar restatement of the reference
+                algorithm) timed on rank 0's host cores over a bounded sample
+                of the same frame (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0
+
+WORKLOADS = {
+    # name: grid, triangles, width, height, tiles per dim, leaf, depth, intensity
+    "cfg3": dict(grid=706, tris=1_000_000, width=3840, height=2160, tiles=16, leaf=8, depth=40,
+                 bounces=4, light_samples=1, intensity=6.0,
+                 label="1M-triangle room mesh (SAH BVH leaf 8), 3840x2160, 4 diffuse bounces, "
+                       "1 light sample, 16x16 tiles"),
+    "small": dict(grid=96, tris=20_000, width=640, height=360, tiles=4, leaf=8, depth=40,
+                  bounces=4, light_samples=1, intensity=6.0,
+                  label="20k-triangle room mesh, 640x360 (functional check only)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel of one frame")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="strict", choices=["strict", "fast", "fp64"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="budget of the CPU-baseline sample (0 disables it)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores)")
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def bytes_per_ray(nodes_visited, tris_fetched, rays):
+    """Algorithmic traffic of one rayCast: 32 B ray in, 16 B hit out, 56 B per
+    interior node whose children are tested (two 24-B boxes + two links) and
+    48 B per leaf triangle fetched."""
+    return 32.0 + 16.0 + 56.0 * nodes_visited / rays + 48.0 * tris_fetched / rays
+
+
+def cpu_baseline(sc, bvh_export, tables, wl, args, tile_list):
+    """Oracle render of a spread sample of tiles at 1 spp on host threads."""
+    from oracle import oracle as O
+    from raytracer_amd import scenes
+    n_threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+    osc = O.Scene(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
+    e = bvh_export
+    osc.set_bvh(e["is_leaf"], e["start"], e["end"], e["bmin"], e["bmax"], e["order"])
+    osc.set_sample_tables(*tables)
+    # visit tiles in a stride that spreads over the frame
+    order = [tile_list[(i * 37) % len(tile_list)] for i in range(len(tile_list))]
+    lock = threading.Lock()
+    state = {"next": 0, "rays": 0, "tiles": 0}
+    deadline = time.perf_counter() + args.cpu_seconds
+
+    def worker():
+        while True:
+            with lock:
+                if state["next"] >= len(order) or time.perf_counter() > deadline:
+                    return
+                t = order[state["next"]]
+                state["next"] += 1
+            tid, x, y, w, h = t
+            d = scenes.make_pass_dict(wl["width"], wl["height"], sc["camera"], spp=1,
+                                      bounces=wl["bounces"], light_samples=wl["light_samples"],
+                                      intensity=wl["intensity"], seed=1, x_offset=x, y_offset=y,
+                                      tile_w=w, tile_h=h, task_id=tid)
+            out = osc.render_tile(O.pass_from_dict(d))
+            with lock:
+                state["rays"] += out["counters"]["rays"]
+                state["tiles"] += 1
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker) for _ in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": state["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": n_threads,
+            "kind": "port",
+            "sample": f"{state['tiles']} of {len(tile_list)} tiles of the same frame at 1 spp, "
+                      f"{state['rays']} rays in {dt:.1f} s, scalar C restatement of the "
+                      f"reference algorithm, one thread per tile worker"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import api, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    mode = {"strict": api.MODE_STRICT_F32, "fast": api.MODE_FAST_F32, "fp64": api.MODE_FP64}[args.mode]
+
+    # ---- scene: generated and built on every rank (deterministic), resident per GPU
+    t0 = time.perf_counter()
+    sc = scenes.room_mesh(wl["grid"], seed=0x5EED0002, total=wl["tris"])
+    mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
+    bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
+    scene = api.Scene(mesh, bvh, local_rank)
+    setup_s = time.perf_counter() - t0
+    tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
+
+    tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
+    my_tiles = [t for i, t in enumerate(tile_list) if i % world == rank]
+    max_px = max(t[3] * t[4] for t in tile_list)
+    n_my = len(my_tiles)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_accum = torch.empty((max_px * 3,), dtype=torch.float32, device="cuda")
+    d_tiles = torch.zeros((n_my, max_px * 4), dtype=torch.uint8, device="cuda")
+    gather_list = None
+    if world > 1 and rank == 0 and not args.no_gather:
+        gather_list = [torch.empty_like(d_tiles) for _ in range(world)]
+    frame = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+
+    def make_pass(tile, spp, seed):
+        tid, x, y, w, h = tile
+        return api.pass_from_dict(scenes.make_pass_dict(
+            wl["width"], wl["height"], sc["camera"], spp=spp, bounces=wl["bounces"],
+            light_samples=wl["light_samples"], intensity=wl["intensity"], seed=seed,
+            x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid))
+
+    def run_step(step, collect):
+        rays = 0
+        kernel_ms = 0.0
+        for i, tile in enumerate(my_tiles):
+            p = make_pass(tile, args.spp, 1 + 1000 * step)
+            st = scene.render_tile_device(p, d_accum.data_ptr(), d_tiles[i].data_ptr(), mode=mode,
+                                          stream=stream, want_stats=True)
+            rays += st["rays"]
+            kernel_ms += st["kernel_ms"]
+        if world > 1 and not args.no_gather:
+            dist.gather(d_tiles, gather_list, dst=0)
+        if rank == 0:
+            srcs = gather_list if gather_list is not None else [d_tiles]
+            for r, buf in enumerate(srcs):
+                for j, (tid, x, y, w, h) in enumerate(tile_list[r::world]):
+                    frame[y:y + h, x:x + w] = buf[j, :w * h * 4].view(h, w, 4)
+        if collect:
+            collect["rays"] += rays
+            collect["kernel_ms"] += kernel_ms
+        return rays
+
+    # ---- bytes/ray of this workload from the counting kernel on a sample tile (untimed)
+    scene.set_counters(True)
+    sample_tile = tile_list[(len(tile_list) // 2) + wl["tiles"] // 2]
+    st = scene.render_tile_device(make_pass(sample_tile, 1, 1), d_accum.data_ptr(),
+                                  d_tiles[0].data_ptr(), mode=mode, stream=stream, want_stats=True)
+    scene.set_counters(False)
+    bpr = bytes_per_ray(st["nodes_visited"], st["tris_fetched"], max(st["rays"], 1))
+    nodes_per_ray = st["nodes_visited"] / max(st["rays"], 1)
+    tris_per_ray = st["tris_fetched"] / max(st["rays"], 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w_ in range(args.warmup):
+        run_step(-1 - w_, None)
+    acc = {"rays": 0, "kernel_ms": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(s, acc)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(acc["rays"]), elapsed, acc["kernel_ms"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        t_max = tot.clone()
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(t_max[1])
+        kernel_ms = float(t_max[2])
+        total_rays = float(tot[0])
+    else:
+        total_rays, kernel_ms = float(acc["rays"]), acc["kernel_ms"]
+
+    if rank == 0:
+        value = total_rays / elapsed / 1e6
+        # roofline of the traversal kernel: this rank's algorithmic bytes over the
+        # time its traversal launches took (HIP events on the launch stream)
+        rank_rays = float(acc["rays"])
+        achieved = rank_rays * bpr / (acc["kernel_ms"] * 1e-3) / 1e9 if acc["kernel_ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/sec (primary+secondary)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if mode != api.MODE_FP64 else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['label']}, {args.spp} spp",
+                       "triangles": int(mesh.n_tris), "bvh_nodes": int(bvh.n_nodes),
+                       "width": wl["width"], "height": wl["height"], "spp": args.spp,
+                       "bounces": wl["bounces"], "light_samples": wl["light_samples"],
+                       "tiles": len(tile_list), "tile_assignment": "block-cyclic",
+                       "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
+                       "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_trace_ref<float>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nodes_per_ray, 2),
+                         "tris_per_ray": round(tris_per_ray, 2),
+                         "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
+                         "note": "scene (64 MB) is served from L2/Infinity Cache, so algorithmic "
+                                 "bytes/s may exceed what HBM itself moves"},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(sc, bvh.export(), tables, wl, args, tile_list)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,10 @@ rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_
 /* Upper bound on camera samples traced together by the tile renderer (sets
  * the size of its device workspace); default 4194304. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
+/* When enabled, render calls that return rt_stats run the counting variant of
+ * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
+ * tris_tested (slower; for the roofline byte model, not for timed runs). */
+rt_status rt_scene_set_counters(rt_scene *scene, int32_t enabled);
 void rt_scene_destroy(rt_scene *scene);
 
 /* ------------------------------------------------------------------ */
@@ -240,6 +244,13 @@ typedef struct rt_pass {            /* models/context.go:40-52 */
 /* camera.go:43-85: projection-plane corner and pixel steps of a pass. */
 rt_status rt_camera_setup(const rt_camera *cam, int32_t total_width, int32_t total_height,
                           float top_left[3], float steps[2]);
+
+/* context.go:245-275 (RenderPass.Initialize: identity camera fallback, debug
+ * light, emission = LightIntensity) + camera.go:43-85, evaluated on the host:
+ * fills the opaque parameter block the kernels receive for a pass (at most 512
+ * bytes).  For tools and tests; the render calls do this themselves. */
+rt_status rt_pass_params(const rt_light *scene_light, const rt_pass *pass, void *out,
+                         size_t out_size);
 
 /* One whole tile: RaysPerPixel samples per pixel, accumulate, resolve.
  * accum_rgb (width*height*3 floats, may be NULL) receives the per-pixel sums

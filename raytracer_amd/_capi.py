@@ -91,11 +91,13 @@ SIGNATURES = {
     "rt_default_sample_table": (C.c_int32, [C.c_int32, C.c_uint64, vp]),
     "rt_scene_set_texture": (C.c_int32, [vp, C.c_int32, vp, C.c_int32, C.c_int32]),
     "rt_scene_set_max_paths": (C.c_int32, [vp, C.c_uint64]),
+    "rt_scene_set_counters": (C.c_int32, [vp, C.c_int32]),
     "rt_scene_destroy": (None, [vp]),
     "rt_trace_rays": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, C.c_int32, C.POINTER(Stats)]),
     "rt_trace_rays_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, vp]),
     "rt_trace_rays_device_counted": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, vp, vp]),
     "rt_camera_setup": (C.c_int32, [C.POINTER(Camera), C.c_int32, C.c_int32, vp, vp]),
+    "rt_pass_params": (C.c_int32, [C.POINTER(Light), C.POINTER(Pass), vp, C.c_size_t]),
     "rt_render_tile": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp, C.POINTER(Stats)]),
     "rt_render_tile_device": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp,
                                           C.POINTER(Stats), vp]),

@@ -205,6 +205,9 @@ class Scene:
     def set_max_paths(self, n):
         check(lib().rt_scene_set_max_paths(self._h, n))
 
+    def set_counters(self, enabled):
+        check(lib().rt_scene_set_counters(self._h, int(enabled)))
+
     # ---- batch rayCast -------------------------------------------------
     def trace_rays(self, rays, mode=MODE_STRICT_F32, counters=False):
         """Host arrays in/out.  rays: RAY_DTYPE array.  Returns (hits, stats dict)."""

@@ -164,6 +164,24 @@ rt_status rt_mesh_light(const rt_mesh *mesh, const rt_bvh *bvh, rt_light *out) {
     RT_GUARD_END
 }
 
+rt_status rt_pass_params(const rt_light *scene_light, const rt_pass *pass, void *out, size_t out_size) {
+    RT_GUARD_BEGIN
+    if (!scene_light || !pass || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    if (out_size < sizeof(rtc::PassParams)) return fail(RT_ERR_INVALID, "output block too small");
+    rtc::PassParams pp;
+    rt_status st = rt::prepare_pass(*scene_light, *pass, pp);
+    if (st != RT_OK) return st;
+    std::memcpy(out, &pp, sizeof pp);
+    return RT_OK;
+    RT_GUARD_END
+}
+
+rt_status rt_scene_set_counters(rt_scene *scene, int32_t enabled) {
+    if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
+    scene->impl->count_traversal = enabled != 0;
+    return RT_OK;
+}
+
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (max_paths < 64 || max_paths > ((uint64_t)1 << 28))

@@ -31,6 +31,7 @@ struct PathBuffers {
     float *brdf_terms;         // (B+1)*P*3
     float *radiance;           // P*3, [sample][pixel]
     unsigned long long *ray_total;
+    unsigned long long *trav_counters;   // 5 x u64, filled when the scene counts traversal work
 };
 
 struct Scene {
@@ -58,6 +59,7 @@ struct Scene {
     std::vector<int32_t> tex_dims;
     // path-tracing workspace (grow-only)
     size_t max_paths_in_flight = (size_t)1 << 22;
+    bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;
     PathBuffers ws{};

@@ -55,6 +55,13 @@ void find_light(const rt_mesh &mesh, const std::vector<int32_t> &order, rt_light
 void camera_setup(const rt_camera &cam, int32_t total_w, int32_t total_h, float top_left[3],
                   float steps[2]);
 
+// context.go:245-275 (RenderPass.Initialize) + camera.go:43-85: everything a
+// pass needs on the device, prepared on the host.
+}  // namespace rt
+namespace rtc { struct PassParams; }
+namespace rt {
+rt_status prepare_pass(const rt_light &scene_light, const rt_pass &pass, rtc::PassParams &pp);
+
 // Scrambled Halton (bases 2 and 3) points in [0,1)^2.
 void default_sample_table(int32_t n, uint64_t seed, double *out);
 

@@ -670,51 +670,6 @@ rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits,
     return RT_OK;
 }
 
-// context.go:245-275 (RenderPass.Initialize) + camera.go:43-85, on the host
-static rt_status prepare_pass(const Scene &sc, const rt_pass &pass, PassParams &pp) {
-    std::memset(&pp, 0, sizeof pp);
-    if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
-    if (pass.camera.rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "Camera.RaysPerPixel must be positive");
-    if (pass.settings.light_sample_rays < 0) return fail(RT_ERR_INVALID, "LightSampleRays is negative");
-    rt_camera cam = pass.camera;
-    const float tr = cam.transform[0] + cam.transform[5] + cam.transform[10] + cam.transform[15];
-    if (std::fabs((double)tr) < 0.001) {
-        std::memset(cam.transform, 0, sizeof cam.transform);
-        cam.transform[0] = cam.transform[5] = cam.transform[10] = cam.transform[15] = 1;
-    }
-    std::memcpy(pp.cam_transform, cam.transform, sizeof pp.cam_transform);
-    const int32_t tw = pass.total_width < 0 ? 0 : pass.total_width;
-    const int32_t th = pass.total_height < 0 ? 0 : pass.total_height;
-    camera_setup(cam, tw, th, pp.top_left, pp.steps);
-    pp.ppd = cam.projection_plane_distance;
-    pp.projection = cam.projection;
-    pp.spp = cam.rays_per_pixel;
-    pp.x_offset = pass.x_offset;
-    pp.y_offset = pass.y_offset;
-    pp.width = pass.width;
-    pp.height = pass.height;
-    pp.rng_seed = pass.rng_seed;
-    pp.L = pass.settings.light_sample_rays;
-    pp.B = pass.settings.bounce_limit & 0xff;
-    rt_light light = sc.light;
-    const rt_settings &st = pass.settings;
-    if (!light.found || st.force_debug_light) {
-        const float *m = st.debug_light_at_camera ? cam.transform : st.debug_light_transform;
-        std::memcpy(light.transform, m, sizeof light.transform);
-        const v3 f = transform_coordinate(v3{0, 0, -1}, m);
-        light.normal[0] = f.x - m[12];
-        light.normal[1] = f.y - m[13];
-        light.normal[2] = f.z - m[14];
-        light.size[0] = light.size[1] = st.debug_light_size;
-    }
-    for (int k = 0; k < 3; ++k) light.emission[k] = 1.0f * st.light_intensity;
-    std::memcpy(pp.light_transform, light.transform, sizeof pp.light_transform);
-    std::memcpy(pp.light_size, light.size, sizeof pp.light_size);
-    std::memcpy(pp.light_emission, light.emission, sizeof pp.light_emission);
-    std::memcpy(pp.light_normal, light.normal, sizeof pp.light_normal);
-    return RT_OK;
-}
-
 // Grow-only workspace for `paths` simultaneous paths with L light samples and
 // B bounces; every buffer is reused across batches and calls.
 static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuffers &w) {
@@ -745,6 +700,7 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.radiance), P * 12));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.ray_total), 64));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.trav_counters), 64));
         sc.ws_paths = paths;
         sc.ws_L = L;
         sc.ws_B = B;
@@ -764,7 +720,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sa
     if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64)
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
     PassParams pp;
-    rt_status st = prepare_pass(sc, pass, pp);
+    rt_status st = prepare_pass(sc.light, pass, pp);
     if (st != RT_OK) return st;
     pp.incremental = incremental ? 1 : 0;
     const size_t pixels = (size_t)pass.width * (size_t)pass.height;
@@ -783,6 +739,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sa
     const DevScene d = dev_view(sc);
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
     HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 5 * sizeof(unsigned long long), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     if (stats) {
@@ -798,7 +755,8 @@ rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sa
             trace_events.emplace_back(a, b);
             HIP_TRY(hipEventRecord(a, stream));
         }
-        rt_status s2 = launch_trace(sc, rays, cap, cnt, hits, mode, nullptr, stream);
+        rt_status s2 = launch_trace(sc, rays, cap, cnt, hits, mode,
+                                    (stats && sc.count_traversal) ? w.trav_counters : nullptr, stream);
         if (s2 != RT_OK) return s2;
         if (stats) HIP_TRY(hipEventRecord(b, stream));
         return RT_OK;
@@ -856,6 +814,14 @@ rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sa
         unsigned long long total = 0;
         HIP_TRY(hipMemcpy(&total, w.ray_total, 8, hipMemcpyDeviceToHost));
         stats->rays = total;
+        if (sc.count_traversal) {
+            unsigned long long c[5];
+            HIP_TRY(hipMemcpy(c, w.trav_counters, sizeof c, hipMemcpyDeviceToHost));
+            stats->nodes_visited = c[1];
+            stats->box_tests = c[2];
+            stats->tris_fetched = c[3];
+            stats->tris_tested = c[4];
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }

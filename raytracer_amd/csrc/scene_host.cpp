@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "gomath.h"
+#include "rt_core.h"
 #include "rt_internal.h"
 
 namespace rt {
@@ -229,5 +230,52 @@ void default_sample_table(int32_t n, uint64_t seed, double *out) {
         }
     }
 }
+
+// context.go:245-275 (RenderPass.Initialize) + camera.go:43-85, on the host
+rt_status prepare_pass(const rt_light &scene_light, const rt_pass &pass, rtc::PassParams &pp) {
+    using rtc::v3;
+    std::memset(&pp, 0, sizeof pp);
+    if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
+    if (pass.camera.rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "Camera.RaysPerPixel must be positive");
+    if (pass.settings.light_sample_rays < 0) return fail(RT_ERR_INVALID, "LightSampleRays is negative");
+    rt_camera cam = pass.camera;
+    const float tr = cam.transform[0] + cam.transform[5] + cam.transform[10] + cam.transform[15];
+    if (std::fabs((double)tr) < 0.001) {
+        std::memset(cam.transform, 0, sizeof cam.transform);
+        cam.transform[0] = cam.transform[5] = cam.transform[10] = cam.transform[15] = 1;
+    }
+    std::memcpy(pp.cam_transform, cam.transform, sizeof pp.cam_transform);
+    const int32_t tw = pass.total_width < 0 ? 0 : pass.total_width;
+    const int32_t th = pass.total_height < 0 ? 0 : pass.total_height;
+    camera_setup(cam, tw, th, pp.top_left, pp.steps);
+    pp.ppd = cam.projection_plane_distance;
+    pp.projection = cam.projection;
+    pp.spp = cam.rays_per_pixel;
+    pp.x_offset = pass.x_offset;
+    pp.y_offset = pass.y_offset;
+    pp.width = pass.width;
+    pp.height = pass.height;
+    pp.rng_seed = pass.rng_seed;
+    pp.L = pass.settings.light_sample_rays;
+    pp.B = pass.settings.bounce_limit & 0xff;
+    rt_light light = scene_light;
+    const rt_settings &st = pass.settings;
+    if (!light.found || st.force_debug_light) {
+        const float *m = st.debug_light_at_camera ? cam.transform : st.debug_light_transform;
+        std::memcpy(light.transform, m, sizeof light.transform);
+        const v3 f = rtc::transform_coordinate(v3{0, 0, -1}, m);
+        light.normal[0] = f.x - m[12];
+        light.normal[1] = f.y - m[13];
+        light.normal[2] = f.z - m[14];
+        light.size[0] = light.size[1] = st.debug_light_size;
+    }
+    for (int k = 0; k < 3; ++k) light.emission[k] = 1.0f * st.light_intensity;
+    std::memcpy(pp.light_transform, light.transform, sizeof pp.light_transform);
+    std::memcpy(pp.light_size, light.size, sizeof pp.light_size);
+    std::memcpy(pp.light_emission, light.emission, sizeof pp.light_emission);
+    std::memcpy(pp.light_normal, light.normal, sizeof pp.light_normal);
+    return RT_OK;
+}
+
 
 }  // namespace rt

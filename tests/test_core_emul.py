@@ -1,0 +1,177 @@
+"""The kernels' arithmetic (raytracer_amd/csrc/rt_core.h, the inline functions
+the HIP kernels call) driven lane-serially on the CPU and compared bit for bit
+with the oracle: traversal in both arithmetic modes, counters, and the whole
+shading / bounce / resolve chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes, _capi
+from util import cornell, oracle_scene, product_mesh, random_rays, rays6
+
+
+def emul_trace(emul, bvh, rays, mode):
+    nodes, tris, _ = bvh.flatten()
+    hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
+    cnt = np.zeros(5, np.uint64)
+    emul.emul_trace(nodes.ctypes.data_as(C.c_void_p), C.c_int32(nodes.shape[0]),
+                    tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                    rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]), C.c_int(mode),
+                    hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+    return hits, cnt
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n,leaf,depth", [(1, 6, 16), (34, 1, 8), (5000, 6, 24), (5000, 6, 3)])
+def test_traversal_bit_exact(product_lib, oracle, emul, mode, n, leaf, depth):
+    sc = scenes.soup(n, seed=4242 + n)
+    bvh = api.Bvh.build(product_mesh(sc), True, leaf, depth)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    rays = random_rays(6000, seed=99)
+    rays["tmax"][::3] = np.float32(1.25)       # bounded (shadow-style) rays too
+    hits, cnt = emul_trace(emul, bvh, rays, mode)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax, mode=mode, counters=True)
+    assert np.array_equal(hits["tri_pos"], ref["tri"])
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(hits["u"].view(np.uint32), ref["u"].view(np.uint32))
+    assert np.array_equal(hits["v"].view(np.uint32), ref["v"].view(np.uint32))
+    c = ref["counters"]
+    assert cnt.tolist() == [c["rays"], c["nodes_visited"], c["box_tests"], c["tris_fetched"],
+                            c["tris_tested"]]
+    assert (hits["tri_pos"] >= 0).sum() > 0 or n == 1
+
+
+def test_degenerate_directions(product_lib, oracle, emul):
+    """Axis-parallel rays (zero and negative-zero components -> +-Inf inverse
+    directions, NaN slabs) on axis-aligned geometry."""
+    sc = cornell()
+    bvh = api.Bvh.build(product_mesh(sc), True, 2, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    o, d = [], []
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            for k in range(40):
+                org = np.array([-0.2 + 0.01 * k, 2.5, -2.0], np.float32)
+                dr = np.zeros(3, np.float32)
+                dr[ax] = sgn
+                dr = dr * np.float32(-1) * np.float32(-1) if k % 2 else dr * np.float32(1)
+                if k % 3 == 0:
+                    dr = (dr * np.float32(-1)) * np.float32(-1)
+                o.append(org)
+                d.append(-dr if k % 4 == 0 else dr)
+    rays = api.make_rays(np.array(o), np.array(d))
+    hits, _ = emul_trace(emul, bvh, rays, 0)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax)
+    assert np.array_equal(hits["tri_pos"], ref["tri"])
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert (hits["tri_pos"] >= 0).sum() > 100
+
+
+def _pass_params(light, p):
+    buf = (C.c_char * 512)()
+    _capi.check(_capi.lib().rt_pass_params(C.byref(light), C.byref(p), buf, 512))
+    return buf
+
+
+def emul_render(emul, mesh, bvh, sc, p, cam_tab, light_tab, sample_begin, sample_count):
+    nodes, tris, mat = bvh.flatten()
+    light = mesh.light(bvh)
+    buf = _pass_params(light, p)
+    pixels = p.width * p.height
+    accum = np.zeros((pixels, 3), np.float32)
+    rad = np.zeros((sample_count, pixels, 3), np.float32)
+    rays = C.c_uint64()
+    kd = np.ascontiguousarray(sc["kd"], np.float32)
+    emul.emul_render(nodes.ctypes.data_as(C.c_void_p), C.c_int32(nodes.shape[0]),
+                     tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                     mat.ctypes.data_as(C.c_void_p), kd.ctypes.data_as(C.c_void_p),
+                     cam_tab.ctypes.data_as(C.c_void_p), C.c_int32(cam_tab.shape[0]),
+                     light_tab.ctypes.data_as(C.c_void_p), C.c_int32(light_tab.shape[0]),
+                     buf, C.c_int32(sample_begin), C.c_int32(sample_count),
+                     accum.ctypes.data_as(C.c_void_p), rad.ctypes.data_as(C.c_void_p),
+                     C.byref(rays))
+    rgba = np.zeros((pixels, 4), np.uint8)
+    emul.emul_resolve(accum.ctypes.data_as(C.c_void_p), C.c_int64(pixels),
+                      C.c_int32(sample_begin + sample_count), C.c_int32(p.settings.gamma_correction),
+                      C.c_float(p.settings.gamma), rgba.ctypes.data_as(C.c_void_p))
+    return accum, rad, rgba, rays.value
+
+
+CORNELL_CAM = {"x": -0.225, "y": 2.55, "z": 6.0}
+
+
+@pytest.mark.parametrize("L,B,spp", [(6, 3, 2), (1, 0, 1), (2, 5, 1)])
+def test_cornell_render_bit_exact(product_lib, oracle, emul, L, B, spp):
+    sc = cornell()
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    cam_tab = api.default_sample_table(12345, 1)
+    light_tab = api.default_sample_table(100001, 2)
+    osc.set_sample_tables(cam_tab, light_tab)
+    d = scenes.make_pass_dict(40, 40, CORNELL_CAM, spp=spp, bounces=B, light_samples=L,
+                              intensity=100.0, seed=7, x_offset=10, y_offset=20, tile_w=24,
+                              tile_h=16, task_id=3)
+    p = api.pass_from_dict(d)
+    po = oracle.pass_from_dict(d)
+    ref = osc.render_tile(po, want_radiance=True)
+    accum, rad, rgba, rays = emul_render(emul, mesh, bvh, sc, p, cam_tab, light_tab, 0, spp)
+    assert np.array_equal(rad.view(np.uint32).reshape(-1), ref["radiance"].view(np.uint32).reshape(-1))
+    assert np.array_equal(accum.view(np.uint32).reshape(-1), ref["accum"].view(np.uint32).reshape(-1))
+    assert np.array_equal(rgba.reshape(-1), ref["rgba"].reshape(-1))
+    assert rays == ref["counters"]["rays"]
+    assert ref["rgba"][..., :3].max() > 50          # the image is lit
+    assert rays > 24 * 16 * spp
+
+
+def test_light_and_camera_setup_match(product_lib, oracle):
+    sc = cornell()
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    a, b = mesh.light(bvh), osc.light()
+    assert a.found == 1 and b.found == 1
+    assert list(a.transform) == list(b.transform) and list(a.size) == list(b.size)
+    assert list(a.normal) == list(b.normal)
+    # the Cornell light faces down and is about 0.525 x 0.65 (half sizes)
+    assert a.normal[1] < -0.99 and abs(a.size[0] - 0.525) < 1e-3 and abs(a.size[1] - 0.65) < 1e-3
+    for proj, w, h, fov in [(0, 250, 250, 45.0), (0, 1920, 1080, 60.0), (1, 640, 480, 45.0)]:
+        d = scenes.make_pass_dict(w, h, CORNELL_CAM, fov=fov, projection=proj)
+        tl, st = api.camera_setup(api.pass_from_dict(d).camera, w, h)
+        tl2, st2 = oracle.camera_setup(oracle.pass_from_dict(d).camera, w, h)
+        assert np.array_equal(tl, tl2) and np.array_equal(st, st2)
+        assert st[0] > 0 and st[1] > 0
+
+
+def test_debug_light_when_scene_has_none(product_lib, oracle, emul):
+    """No "Light" material -> RenderPass.Initialize makes a debug light at the
+    camera or at the given transform (context.go:257-271)."""
+    sc = scenes.soup(300, seed=8)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    cam_tab = api.default_sample_table(97, 1)
+    light_tab = api.default_sample_table(211, 2)
+    osc.set_sample_tables(cam_tab, light_tab)
+    d = scenes.make_pass_dict(32, 24, {"x": 0, "y": 0, "z": 4}, spp=1, bounces=2, light_samples=2,
+                              intensity=30.0, seed=3, gamma_on=False)
+    d["Settings"]["DebugLightAtCamera"] = True
+    d["Settings"]["DebugLightSize"] = 0.5
+    ref = osc.render_tile(oracle.pass_from_dict(d), want_radiance=True)
+    accum, rad, rgba, rays = emul_render(emul, mesh, bvh, sc, api.pass_from_dict(d), cam_tab,
+                                         light_tab, 0, 1)
+    assert np.array_equal(accum.view(np.uint32).reshape(-1), ref["accum"].view(np.uint32).reshape(-1))
+    assert np.array_equal(rgba.reshape(-1), ref["rgba"].reshape(-1))
+
+
+def test_default_sample_table_is_low_discrepancy(product_lib):
+    t = api.default_sample_table(4096, 5)
+    assert t.min() >= 0 and t.max() < 1
+    # every cell of a 16x16 grid is hit by a scrambled Halton prefix of 4096
+    cells = np.unique((t[:, 0] * 16).astype(int) * 16 + (t[:, 1] * 16).astype(int))
+    assert len(cells) == 256
+    assert abs(t.mean() - 0.5) < 0.01
+    assert not np.array_equal(t, api.default_sample_table(4096, 6))

@@ -1,0 +1,163 @@
+"""GPU parity of the batch ray cast (rt_trace_rays through the C ABI) against
+the oracle: hit ids, t, u, v bit-exact in the float32 and float64 modes, the
+traversal counters, and the edge cases of the domain."""
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from util import cornell, oracle_scene, product_mesh, random_rays, rays6
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(hits, ref, exact_uv=True):
+    assert np.array_equal(hits["tri_pos"], ref["tri"])
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    if exact_uv:
+        assert np.array_equal(hits["u"].view(np.uint32), ref["u"].view(np.uint32))
+        assert np.array_equal(hits["v"].view(np.uint32), ref["v"].view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def soup20k(product_lib, oracle, gpu_device):
+    sc = scenes.soup(20000, seed=0x5EED0001)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 32)
+    return sc, mesh, bvh, api.Scene(mesh, bvh, gpu_device), oracle_scene(oracle, sc, bvh_export=bvh.export())
+
+
+@pytest.mark.parametrize("mode", [api.MODE_STRICT_F32, api.MODE_FP64])
+def test_incoherent_rays_bit_exact(soup20k, mode):
+    _, _, _, scene, osc = soup20k
+    rays = random_rays(200000, seed=5)
+    rays["tmax"][::5] = np.float32(0.75)
+    hits, st = scene.trace_rays(rays, mode=mode, counters=True)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax, mode=mode, counters=True)
+    _check(hits, ref)
+    c = ref["counters"]
+    assert (st["rays"], st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]) == \
+        (c["rays"], c["nodes_visited"], c["box_tests"], c["tris_fetched"], c["tris_tested"])
+    assert (hits["tri_pos"] >= 0).mean() > 0.2
+
+
+def test_primary_rays_config1_shape(soup20k):
+    """Coherent camera rays (the 100k-soup / 1080p configuration at reduced
+    size): float32 bit-exact, and the float64 validation mode differs from the
+    float32 oracle only on a counted set of edge-grazing rays."""
+    _, _, _, scene, osc = soup20k
+    o, d = scenes.primary_rays(480, 270, {"x": 0.0, "y": 0.0, "z": 4.0})
+    rays = api.make_rays(o, d)
+    r6, tmax = rays6(rays)
+    ref32 = osc.trace_rays(r6, tmax, mode=0)
+    hits32, _ = scene.trace_rays(rays, mode=api.MODE_STRICT_F32)
+    _check(hits32, ref32)
+    hits64, _ = scene.trace_rays(rays, mode=api.MODE_FP64)
+    ref64 = osc.trace_rays(r6, tmax, mode=1)
+    _check(hits64, ref64)
+    grazing = int((hits64["tri_pos"] != ref32["tri"]).sum())
+    assert grazing <= 0.001 * len(rays), grazing
+    same = hits64["tri_pos"] == ref32["tri"]
+    hit = same & (ref32["tri"] >= 0)
+    rel = np.abs(hits64["t"][hit] - ref32["t"][hit]) / ref32["t"][hit]
+    assert rel.max() < 1e-5
+
+
+def test_empty_and_ragged_batches(soup20k):
+    _, _, _, scene, osc = soup20k
+    hits, st = scene.trace_rays(np.zeros(0, api.RAY_DTYPE))
+    assert len(hits) == 0 and st["rays"] == 0
+    for n in (1, 63, 64, 65, 257, 1000):
+        rays = random_rays(n, seed=n)
+        hits, _ = scene.trace_rays(rays)
+        r6, tmax = rays6(rays)
+        _check(hits, osc.trace_rays(r6, tmax))
+
+
+def test_miss_reports_tmax_and_minus_one(soup20k):
+    _, _, _, scene, _ = soup20k
+    rays = api.make_rays([[50, 50, 50]] * 3, [[1, 0, 0]] * 3, tmax=[api.F32_MAX, 2.5, 0.0])
+    hits, _ = scene.trace_rays(rays)
+    assert hits["tri_pos"].tolist() == [-1, -1, -1]
+    assert hits["t"].tolist() == [float(api.F32_MAX), 2.5, 0.0]
+
+
+def test_single_leaf_root_and_tiny_scenes(product_lib, oracle, gpu_device):
+    for n, use_bvh in [(1, True), (5, True), (40, False)]:
+        sc = scenes.soup(n, seed=31 + n, extent=0.3, size=0.4)
+        mesh = product_mesh(sc)
+        bvh = api.Bvh.build(mesh, use_bvh, 6, 16)
+        scene = api.Scene(mesh, bvh, gpu_device)
+        osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+        rays = random_rays(5000, seed=n, extent=1.0)
+        hits, _ = scene.trace_rays(rays)
+        r6, tmax = rays6(rays)
+        ref = osc.trace_rays(r6, tmax)
+        _check(hits, ref)
+        assert (hits["tri_pos"] >= 0).sum() > 0
+
+
+def test_axis_aligned_rays_on_cornell(product_lib, oracle, gpu_device):
+    """+-0 direction components (Inf inverse, NaN slabs) and exact box-face
+    ties on the axis-aligned Cornell walls."""
+    sc = cornell()
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 2, 16)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    o, d = [], []
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            for k in range(200):
+                o.append([-2.5 + 0.025 * k, 0.1 + 0.025 * k, -5.0 + 0.02 * k])
+                dr = np.zeros(3, np.float32)
+                dr[ax] = sgn
+                d.append(dr * np.float32(-1) if k % 2 else dr)
+    rays = api.make_rays(np.array(o, np.float32), np.array(d, np.float32))
+    hits, _ = scene.trace_rays(rays)
+    r6, tmax = rays6(rays)
+    _check(hits, osc.trace_rays(r6, tmax))
+    assert (hits["tri_pos"] >= 0).sum() > 300
+
+
+def test_subnormal_and_huge_values(product_lib, oracle, gpu_device):
+    """Denormal direction components must not be flushed; huge coordinates must
+    overflow the same way."""
+    sc = scenes.soup(2000, seed=12)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 24)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    rays = random_rays(4000, seed=3)
+    rays["dir"][::4, 0] = np.float32(1e-41)
+    rays["dir"][1::4, 1] = np.float32(-1e-42)
+    rays["origin"][2::16] *= np.float32(1e30)
+    rays["dir"][3::16] *= np.float32(1e20)
+    hits, _ = scene.trace_rays(rays)
+    r6, tmax = rays6(rays)
+    _check(hits, osc.trace_rays(r6, tmax))
+
+
+def test_device_pointer_entry_point(soup20k):
+    import torch
+    _, _, _, scene, osc = soup20k
+    rays = random_rays(100000, seed=77)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
+    d_hits = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.trace_rays_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    hits = d_hits.cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
+    r6, tmax = rays6(rays)
+    _check(hits, osc.trace_rays(r6, tmax))
+
+
+def test_scene_info_and_errors(soup20k, gpu_device):
+    sc, mesh, bvh, scene, _ = soup20k
+    info = scene.info()
+    assert info["n_tris"] == 20000 and info["n_nodes"] == bvh.n_nodes
+    assert info["node_bytes"] == 32 * bvh.n_nodes and info["tri_bytes"] == 48 * 20000
+    with pytest.raises(api._capi.RtError):
+        api.Scene(mesh, bvh, 999)
+    with pytest.raises(api._capi.RtError):
+        scene.trace_rays(random_rays(10, seed=1), mode=17)
