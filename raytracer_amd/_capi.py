@@ -118,6 +118,12 @@ def lib():
             raise RuntimeError(
                 f"{path} is missing: build it with `python -m raytracer_amd.build` "
                 "(hipcc, gfx950). There is no fallback implementation.")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 and
+        # loads it by path.  Importing torch first makes the loader resolve this
+        # library's libamdhip64.so.7 dependency to that already-loaded copy
+        # instead of mapping a second runtime from /opt/rocm (two runtimes in
+        # one process see no devices).
+        import torch  # noqa: F401
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError here = header/library mismatch
