@@ -53,7 +53,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel of one frame")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="strict", choices=["strict", "fast", "fp64"])
+    ap.add_argument("--mode", default="fast", choices=["strict", "fast", "fp64"],
+                    help="traversal kernel: fast = ordered traversal (default), strict = the "
+                         "reference's visit order (bit-exact mode), fp64 = validation mode")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores)")
@@ -145,11 +147,13 @@ def main():
 
     tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
     my_tiles = [t for i, t in enumerate(tile_list) if i % world == rank]
-    max_px = max(t[3] * t[4] for t in tile_list)
-    n_my = len(my_tiles)
+    # every rank's tile images live back to back in one buffer; ranks own equal
+    # numbers of pixels only when the tile grid divides evenly, so pad to the maximum
+    px_of = [sum(t[3] * t[4] for i, t in enumerate(tile_list) if i % world == r) for r in range(world)]
+    my_px, max_px = px_of[rank], max(px_of)
     stream = torch.cuda.current_stream().cuda_stream
-    d_accum = torch.empty((max_px * 3,), dtype=torch.float32, device="cuda")
-    d_tiles = torch.zeros((n_my, max_px * 4), dtype=torch.uint8, device="cuda")
+    d_accum = torch.empty((max(my_px, 1) * 3,), dtype=torch.float32, device="cuda")
+    d_tiles = torch.zeros((max_px * 4,), dtype=torch.uint8, device="cuda")
     gather_list = None
     if world > 1 and rank == 0 and not args.no_gather:
         gather_list = [torch.empty_like(d_tiles) for _ in range(world)]
@@ -163,21 +167,21 @@ def main():
             x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid))
 
     def run_step(step, collect):
-        rays = 0
-        kernel_ms = 0.0
-        for i, tile in enumerate(my_tiles):
-            p = make_pass(tile, args.spp, 1 + 1000 * step)
-            st = scene.render_tile_device(p, d_accum.data_ptr(), d_tiles[i].data_ptr(), mode=mode,
-                                          stream=stream, want_stats=True)
-            rays += st["rays"]
-            kernel_ms += st["kernel_ms"]
+        # all of this rank's tiles in one call: one ray queue per path depth for the
+        # whole tile set, so small tiles still fill the GPU
+        passes = [make_pass(tile, args.spp, 1 + 1000 * step) for tile in my_tiles]
+        st = scene.render_tiles_device(passes, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
+                                       stream=stream, want_stats=True)
+        rays, kernel_ms = st["rays"], st["kernel_ms"]
         if world > 1 and not args.no_gather:
             dist.gather(d_tiles, gather_list, dst=0)
         if rank == 0:
             srcs = gather_list if gather_list is not None else [d_tiles]
             for r, buf in enumerate(srcs):
-                for j, (tid, x, y, w, h) in enumerate(tile_list[r::world]):
-                    frame[y:y + h, x:x + w] = buf[j, :w * h * 4].view(h, w, 4)
+                off = 0
+                for (tid, x, y, w, h) in tile_list[r::world]:
+                    frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
+                    off += w * h * 4
         if collect:
             collect["rays"] += rays
             collect["kernel_ms"] += kernel_ms
@@ -187,7 +191,7 @@ def main():
     scene.set_counters(True)
     sample_tile = tile_list[(len(tile_list) // 2) + wl["tiles"] // 2]
     st = scene.render_tile_device(make_pass(sample_tile, 1, 1), d_accum.data_ptr(),
-                                  d_tiles[0].data_ptr(), mode=mode, stream=stream, want_stats=True)
+                                  d_tiles.data_ptr(), mode=mode, stream=stream, want_stats=True)
     scene.set_counters(False)
     bpr = bytes_per_ray(st["nodes_visited"], st["tris_fetched"], max(st["rays"], 1))
     nodes_per_ray = st["nodes_visited"] / max(st["rays"], 1)
@@ -243,7 +247,8 @@ def main():
                        "tiles": len(tile_list), "tile_assignment": "block-cyclic",
                        "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
                        "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_ref<float>",
+            "roofline": {"bound": "hbm", "kernel": {"fast": "k_trace_fast", "strict": "k_trace_ref<float>",
+                                                   "fp64": "k_trace_ref<double>"}[args.mode],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nodes_per_ray, 2),

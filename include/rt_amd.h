@@ -107,6 +107,15 @@ void rt_free(void *p);
 rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float *tris,
                      int32_t *tri_material);
 
+/* The second flat view used by RT_MODE_FAST_F32: one 64-byte record per
+ * interior node holding both children's boxes and references, 16 floats each:
+ * (L.min.xyz, L.max.xyz, R.min.xyz, R.max.xyz, bits L.ref, bits R.ref, 0, 0);
+ * ref = record index, or for a leaf 0x80000000 | count << 24 | first triangle.
+ * Call with records == NULL to get the count.  *root_ref is the ref traversal
+ * starts from. */
+rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *records,
+                             size_t capacity_records, size_t *n_records, uint32_t *root_ref);
+
 /* ------------------------------------------------------------------ */
 /* Scene (device side): flattened node / triangle buffers in HBM.      */
 /* Replaces the pointer tree + []*Triangle of models/bvh.go:13-29 and  */
@@ -263,6 +272,16 @@ rt_status rt_render_tile(rt_scene *scene, const rt_pass *pass, int32_t mode,
  * except for the ray-count read-back when stats != NULL. */
 rt_status rt_render_tile_device(rt_scene *scene, const rt_pass *pass, int32_t mode,
                                 void *d_accum, void *d_rgba, rt_stats *stats, void *stream);
+/* Several tiles of one frame in one call: what a worker does by calling
+ * render() once per task it pulls (frontend Renderer.js:565-568), batched so
+ * that small tiles still fill the GPU.  The passes must share camera, settings
+ * and frame size; offsets, sizes, TaskID and RNGSeed differ.  Each tile's
+ * result equals its own rt_render_tile_device call bit for bit.  Pixels of tile
+ * i start at offset sum_{j<i} width_j*height_j in d_accum (x3 floats) and
+ * d_rgba (x4 bytes). */
+rt_status rt_render_tiles_device(rt_scene *scene, const rt_pass *passes, int32_t n_passes,
+                                 int32_t mode, void *d_accum, void *d_rgba, rt_stats *stats,
+                                 void *stream);
 /* main.go:234-306 incrementalRender: trace samples [sample_begin,
  * sample_begin+sample_count) of every pixel into the caller-owned device
  * accumulation buffer (NOT zeroed), then resolve with divisor

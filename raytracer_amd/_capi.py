@@ -83,6 +83,8 @@ SIGNATURES = {
     "rt_bvh_destroy": (None, [vp]),
     "rt_free": (None, [vp]),
     "rt_flatten": (C.c_int32, [C.POINTER(Mesh), vp, vp, vp, vp]),
+    "rt_flatten_ordered": (C.c_int32, [C.POINTER(Mesh), vp, vp, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "rt_mesh_light": (C.c_int32, [C.POINTER(Mesh), vp, C.POINTER(Light)]),
     "rt_scene_create": (C.c_int32, [C.POINTER(Mesh), vp, C.c_int32, C.POINTER(vp)]),
     "rt_scene_info_get": (C.c_int32, [vp, C.POINTER(SceneInfo)]),
@@ -101,6 +103,8 @@ SIGNATURES = {
     "rt_render_tile": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp, C.POINTER(Stats)]),
     "rt_render_tile_device": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp,
                                           C.POINTER(Stats), vp]),
+    "rt_render_tiles_device": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, C.c_int32, vp, vp,
+                                           C.POINTER(Stats), vp]),
     "rt_render_accumulate": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, C.c_int32, C.c_int32,
                                          vp, vp, C.POINTER(Stats), vp]),
     "rt_resolve_device": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.c_int32, C.c_float, vp, vp]),

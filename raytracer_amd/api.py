@@ -136,6 +136,16 @@ class Bvh:
         check(lib().rt_flatten(C.byref(self.mesh.c), self._h, _ptr(nodes), _ptr(tris), _ptr(mat)))
         return nodes, tris, mat
 
+    def flatten_ordered(self):
+        """(records (n,16) f32, root_ref) of the ordered-traversal view."""
+        n, root = C.c_size_t(), C.c_uint32()
+        check(lib().rt_flatten_ordered(C.byref(self.mesh.c), self._h, None, 0, C.byref(n),
+                                       C.byref(root)))
+        rec = np.zeros((n.value, 16), np.float32)
+        check(lib().rt_flatten_ordered(C.byref(self.mesh.c), self._h, _ptr(rec), n.value,
+                                       C.byref(n), C.byref(root)))
+        return rec, root.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().rt_bvh_destroy(self._h)
@@ -243,6 +253,17 @@ class Scene:
         st = Stats() if want_stats else None
         check(lib().rt_render_tile_device(self._h, C.byref(p), mode, d_accum_ptr, d_rgba_ptr,
                                           C.byref(st) if st is not None else None, stream))
+        return st.as_dict() if st is not None else None
+
+    def render_tiles_device(self, passes, d_accum_ptr, d_rgba_ptr, mode=MODE_STRICT_F32,
+                            stream=None, want_stats=False):
+        """Several tiles of one frame in one call; pixels of tile i follow those of
+        tile i-1 in both device buffers."""
+        arr = (Pass * len(passes))(*passes)
+        st = Stats() if want_stats else None
+        check(lib().rt_render_tiles_device(self._h, arr, len(passes), mode, d_accum_ptr,
+                                           d_rgba_ptr, C.byref(st) if st is not None else None,
+                                           stream))
         return st.as_dict() if st is not None else None
 
     def render_accumulate(self, p, sample_begin, sample_count, d_accum_ptr, d_rgba_ptr,

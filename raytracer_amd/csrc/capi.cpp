@@ -152,6 +152,26 @@ rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float
     RT_GUARD_END
 }
 
+rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *records,
+                             size_t capacity_records, size_t *n_records, uint32_t *root_ref) {
+    RT_GUARD_BEGIN
+    if (!bvh || !n_records || !root_ref) return fail(RT_ERR_INVALID, "NULL argument");
+    rt_status st = rt::check_mesh(mesh);
+    if (st != RT_OK) return st;
+    rt::FlatScene flat;
+    st = rt::flatten(*mesh, bvh->bvh, flat);
+    if (st != RT_OK) return st;
+    if (!flat.fast_ok) return fail(RT_ERR_INVALID, "tree does not fit the ordered-traversal encoding (more than 2^24-2 triangles or deeper than 60)");
+    *n_records = flat.pairs.size() / 16;
+    *root_ref = flat.fast_root;
+    if (records) {
+        if (capacity_records < *n_records) return fail(RT_ERR_INVALID, "records buffer too small");
+        std::memcpy(records, flat.pairs.data(), flat.pairs.size() * 4);
+    }
+    return RT_OK;
+    RT_GUARD_END
+}
+
 rt_status rt_mesh_light(const rt_mesh *mesh, const rt_bvh *bvh, rt_light *out) {
     RT_GUARD_BEGIN
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
@@ -310,7 +330,7 @@ rt_status rt_render_tile_device(rt_scene *scene, const rt_pass *pass, int32_t mo
                                 void *d_rgba, rt_stats *stats, void *stream) {
     RT_GUARD_BEGIN
     if (!scene || !scene->impl || !pass) return fail(RT_ERR_INVALID, "NULL argument");
-    return rt::render_accumulate(*scene->impl, *pass, mode, 0, pass->camera.rays_per_pixel, false,
+    return rt::render_accumulate(*scene->impl, pass, 1, mode, 0, pass->camera.rays_per_pixel, false,
                                  true, static_cast<float *>(d_accum),
                                  static_cast<uint8_t *>(d_rgba), stats,
                                  static_cast<hipStream_t>(stream));
@@ -322,7 +342,20 @@ rt_status rt_render_accumulate(rt_scene *scene, const rt_pass *pass, int32_t mod
                                void *d_rgba, rt_stats *stats, void *stream) {
     RT_GUARD_BEGIN
     if (!scene || !scene->impl || !pass) return fail(RT_ERR_INVALID, "NULL argument");
-    return rt::render_accumulate(*scene->impl, *pass, mode, sample_begin, sample_count, true, false,
+    return rt::render_accumulate(*scene->impl, pass, 1, mode, sample_begin, sample_count, true, false,
+                                 static_cast<float *>(d_accum), static_cast<uint8_t *>(d_rgba),
+                                 stats, static_cast<hipStream_t>(stream));
+    RT_GUARD_END
+}
+
+rt_status rt_render_tiles_device(rt_scene *scene, const rt_pass *passes, int32_t n_passes,
+                                 int32_t mode, void *d_accum, void *d_rgba, rt_stats *stats,
+                                 void *stream) {
+    RT_GUARD_BEGIN
+    if (!scene || !scene->impl || !passes) return fail(RT_ERR_INVALID, "NULL argument");
+    if (n_passes < 1) return fail(RT_ERR_INVALID, "no pass given");
+    return rt::render_accumulate(*scene->impl, passes, n_passes, mode, 0,
+                                 passes[0].camera.rays_per_pixel, false, true,
                                  static_cast<float *>(d_accum), static_cast<uint8_t *>(d_rgba),
                                  stats, static_cast<hipStream_t>(stream));
     RT_GUARD_END

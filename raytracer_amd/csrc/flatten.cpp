@@ -3,11 +3,91 @@
 // models/triangle.go:12-31: []*Triangle) into the two flat, 16-byte-aligned
 // record arrays the kernels read (layout: rt_core.h, DevScene).
 #include <cstring>
+#include <limits>
 
 #include "rt_core.h"
 #include "rt_internal.h"
 
 namespace rt {
+
+namespace {
+
+// Child-pair records for the ordered traversal.  Leaves larger than the 7-bit
+// count field are cut into a chain of synthetic interior records that reuse the
+// leaf's box; an empty leaf (the reference can create one, bvh.go:94-100 with
+// BVHMaxLeafSize 1) gets an inverted box that no ray enters.
+struct PairBuilder {
+    const Bvh &bvh;
+    const std::vector<int32_t> &skip;
+    std::vector<float> &pairs;
+    const float inf;
+
+    uint32_t new_record() {
+        pairs.resize(pairs.size() + 16, 0.0f);
+        return (uint32_t)(pairs.size() / 16 - 1);
+    }
+    void set_child(uint32_t rec, int side, const float mn[3], const float mx[3], uint32_t ref) {
+        float *p = &pairs[(size_t)rec * 16];
+        if (side == 0) {
+            p[0] = mn[0]; p[1] = mn[1]; p[2] = mn[2]; p[3] = mx[0]; p[4] = mx[1]; p[5] = mx[2];
+        } else {
+            p[6] = mn[0]; p[7] = mn[1]; p[8] = mn[2]; p[9] = mx[0]; p[10] = mx[1]; p[11] = mx[2];
+        }
+        p[12 + side] = rtc::i2f((int32_t)ref);
+    }
+    // reference to a triangle range with the given box
+    uint32_t leaf_ref(int32_t start, int32_t count, const float mn[3], const float mx[3]) {
+        if (count <= rtc::kFastMaxLeaf)
+            return rtc::kLeafBit | ((uint32_t)count << 24) | (uint32_t)start;
+        const uint32_t rec = new_record();
+        const int32_t half = count / 2;
+        const uint32_t l = leaf_ref(start, half, mn, mx);
+        const uint32_t r = leaf_ref(start + half, count - half, mn, mx);
+        set_child(rec, 0, mn, mx, l);
+        set_child(rec, 1, mn, mx, r);
+        return rec;
+    }
+    uint32_t child_ref(int32_t node, float mn[3], float mx[3]) {
+        std::memcpy(mn, &bvh.bmin[3 * (size_t)node], 12);
+        std::memcpy(mx, &bvh.bmax[3 * (size_t)node], 12);
+        if (!bvh.is_leaf[(size_t)node]) return record_of[(size_t)node];
+        const int32_t start = bvh.start[(size_t)node];
+        const int32_t count = bvh.end[(size_t)node] - start + 1;
+        if (count <= 0) {
+            for (int k = 0; k < 3; ++k) { mn[k] = inf; mx[k] = -inf; }
+            return rtc::kLeafBit;   // count 0
+        }
+        return leaf_ref(start, count, mn, mx);
+    }
+    std::vector<uint32_t> record_of;   // interior node -> record index
+};
+
+void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t> &skip, FlatScene &out) {
+    out.pairs.clear();
+    out.fast_ok = false;
+    out.fast_root = 0;
+    if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
+    PairBuilder b{bvh, skip, out.pairs, std::numeric_limits<float>::infinity(), {}};
+    const int32_t nn = bvh.n_nodes;
+    b.record_of.assign((size_t)nn, 0);
+    for (int32_t i = 0; i < nn; ++i)
+        if (!bvh.is_leaf[(size_t)i]) b.record_of[(size_t)i] = b.new_record();
+    float mn[3], mx[3];
+    for (int32_t i = 0; i < nn; ++i) {
+        if (bvh.is_leaf[(size_t)i]) continue;
+        const int32_t l = i + 1, r = skip[(size_t)l];
+        const uint32_t rec = b.record_of[(size_t)i];
+        const uint32_t lref = b.child_ref(l, mn, mx);
+        b.set_child(rec, 0, mn, mx, lref);
+        const uint32_t rref = b.child_ref(r, mn, mx);
+        b.set_child(rec, 1, mn, mx, rref);
+    }
+    out.fast_root = b.child_ref(0, mn, mx);   // the root is entered without a box test
+    if (out.pairs.empty()) out.pairs.resize(16, 0.0f);
+    out.fast_ok = true;
+}
+
+}  // namespace
 
 rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out) {
     using rtc::f4;
@@ -69,6 +149,7 @@ rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out) {
         out.tri_mat[(size_t)pos] = mat | (mesh.is_light[mat] ? rtc::kLightBit : 0);
         if (mesh.texcoords) std::memcpy(&out.tri_uv[6 * (size_t)pos], mesh.texcoords + 6 * (size_t)id, 24);
     }
+    build_pairs(mesh, bvh, skip, out);
     return RT_OK;
 }
 

@@ -63,12 +63,24 @@ struct DevScene {
     const int32_t *mat_tex;     // n_materials texture slot or -1 (nullptr: none)
     const uint8_t *const *tex_data;   // per slot RGBA8 rows
     const int32_t *tex_dim;     // per slot (w, h)
+    // Ordered-traversal view of the same tree (fast mode): one 64-byte record
+    // per interior node holding BOTH children's boxes and references,
+    //   [0] = (L.min.xyz, L.max.x) [1] = (L.max.yz, R.min.xy) [2] = (R.min.z, R.max.xyz)
+    //   [3] = (bits L.ref, bits R.ref, 0, 0)
+    // ref: interior -> record index; leaf -> kLeafBit | count << 24 | first triangle.
+    const f4 *pairs;
+    uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
+    int32_t fast_ok;            // 0: tree does not fit the fast encoding
     const double *cam_tab;      // n_cam * 2
     const double *light_tab;    // n_light * 2
     int32_t n_nodes, n_tris, n_cam, n_light;
 };
 
 constexpr int32_t kLightBit = 1 << 30;
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kRefDone = 0xFFFFFFFFu;   // empty-stack marker (count 127, start 2^24-1 is never built)
+constexpr int32_t kFastMaxLeaf = 126;
+constexpr int32_t kFastMaxTris = (1 << 24) - 2;
 
 // ---------------------------------------------------------------------------
 // Ray state for the reference-order traversal.
@@ -116,7 +128,10 @@ struct Hit {
 // bvh.go:120-131 for one triangle record: back-face cull, triangle.go:78-103,
 // then "t > 0 && t < tmin" (first visited wins ties).  Returns true when the
 // Moller-Trumbore test was evaluated (for the counters).
-template <typename Real>
+// TIE_BY_POS (fast mode only): an exactly equal t also wins when the triangle
+// sits earlier in the array, which is what the reference's left-first order
+// yields for ties, so the result does not depend on the visiting order.
+template <typename Real, bool TIE_BY_POS = false>
 RT_HD bool tri_test(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2, int32_t pos,
                     Hit<Real> &h) {
     const Real nx = (Real)q0.x, ny = (Real)q0.y, nz = (Real)q0.z;
@@ -140,7 +155,7 @@ RT_HD bool tri_test(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2
     const Real v = (r.dx * qx + r.dy * qy + r.dz * qz) * invdet;
     if (v < 0 || u + v > 1) return true;
     const Real t = (wx * qx + wy * qy + wz * qz) * invdet;
-    if (t > 0 && t < h.t) {
+    if (t > 0 && (t < h.t || (TIE_BY_POS && t == h.t && pos < h.pos))) {
         h.t = t;
         h.u = u;
         h.v = v;
@@ -181,6 +196,71 @@ RT_HD void traverse_ref_order(const DevScene &s, const Ray<Real> &r, Hit<Real> &
             if (COUNT && pass) c->nodes_visited++;
             node = pass ? node + 1 : a;
         }
+    }
+}
+
+// The fast mode's ordered traversal, lane-serial form: nearer child first, the
+// farther one stacked with its entry distance and dropped at pop time once a
+// closer hit exists.  Box slabs use the reference's (bound - origin) * invDir;
+// the triangle test is tri_test() unchanged, so t, u, v of a given triangle are
+// bit-identical to the reference order's.
+template <bool COUNT>
+RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &h, Counters *c) {
+    uint32_t stack_ref[64];
+    float stack_t[64];
+    int32_t sp = 0;
+    uint32_t cur = s.fast_root;
+    for (;;) {
+        while ((cur & kLeafBit) == 0) {
+            const f4 *q = s.pairs + 4 * (size_t)cur;
+            const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (COUNT) { c->nodes_visited++; c->box_tests += 2; }
+            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.w - r.ox) * r.ix;
+            const float ly0 = (q0.y - r.oy) * r.iy, ly1 = (q1.x - r.oy) * r.iy;
+            const float lz0 = (q0.z - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
+            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q2.y - r.ox) * r.ix;
+            const float ry0 = (q1.w - r.oy) * r.iy, ry1 = (q2.z - r.oy) * r.iy;
+            const float rz0 = (q2.x - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
+            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+            const bool hl = ln <= lf && ln < h.t && lf > 0;
+            const bool hr = rn <= rf && rn < h.t && rf > 0;
+            const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
+            if (hl && hr) {
+                const bool left_first = ln <= rn;
+                stack_ref[sp] = left_first ? rref : lref;
+                stack_t[sp] = left_first ? rn : ln;
+                sp++;
+                cur = left_first ? lref : rref;
+            } else if (hl) {
+                cur = lref;
+            } else if (hr) {
+                cur = rref;
+            } else {
+                cur = kRefDone;
+                while (sp > 0) {
+                    sp--;
+                    if (stack_t[sp] < h.t) { cur = stack_ref[sp]; break; }
+                }
+            }
+        }
+        if (cur == kRefDone) return;
+        const int32_t start = (int32_t)(cur & 0xFFFFFFu);
+        const int32_t count = (int32_t)((cur >> 24) & 0x7Fu);
+        for (int32_t k = 0; k < count; ++k) {
+            const f4 *q = s.tris + 3 * (size_t)(start + k);
+            if (COUNT) c->tris_fetched++;
+            const bool tested = tri_test<float, true>(r, q[0], q[1], q[2], start + k, h);
+            if (COUNT && tested) c->tris_tested++;
+        }
+        cur = kRefDone;
+        while (sp > 0) {
+            sp--;
+            if (stack_t[sp] < h.t) { cur = stack_ref[sp]; break; }
+        }
+        if (cur == kRefDone) return;
     }
 }
 
@@ -244,19 +324,71 @@ struct PassParams {
     float light_emission[3];
     float light_normal[3];
     int32_t incremental;            // path index = s*pixels + i instead of i*spp + s
+    // Several tiles of one frame traced together (same camera and settings):
+    // n_tiles > 0 replaces x_offset/y_offset/width/height/rng_seed by a table.
+    int32_t n_tiles;
+    const struct TileDesc *tiles;
 };
 
+// One tile of a multi-tile pass; pixels of all tiles are numbered consecutively,
+// tile after tile (pix_start = number of pixels in the tiles before this one).
+struct TileDesc {
+    int32_t x_offset, y_offset, width, height;
+    int64_t rng_seed;
+    uint32_t pix_start;
+    uint32_t pad;
+};
+
+// Where a camera sample lives: its tile's offsets and seed, its pixel inside the
+// tile and its path index (the reference's running ray index `ri`, main.go:132).
+struct PathCtx {
+    int32_t x_offset, y_offset, x, y;
+    int64_t rng_seed;
+    uint64_t path_index;
+};
+
+RT_HD PathCtx locate_path(const PassParams &p, uint32_t pix, uint32_t sample) {
+    PathCtx c;
+    int32_t w = p.width, h = p.height;
+    uint32_t local = pix;
+    c.x_offset = p.x_offset;
+    c.y_offset = p.y_offset;
+    c.rng_seed = p.rng_seed;
+    if (p.n_tiles > 0) {
+        int32_t lo = 0, hi = p.n_tiles - 1;   // last tile whose pix_start <= pix
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (p.tiles[mid].pix_start <= pix) lo = mid; else hi = mid - 1;
+        }
+        const TileDesc t = p.tiles[lo];
+        w = t.width;
+        h = t.height;
+        local = pix - t.pix_start;
+        c.x_offset = t.x_offset;
+        c.y_offset = t.y_offset;
+        c.rng_seed = t.rng_seed;
+    }
+    c.x = (int32_t)(local % (uint32_t)w);
+    c.y = (int32_t)(local / (uint32_t)w);
+    const uint64_t pixels = (uint64_t)w * (uint64_t)h;
+    c.path_index = p.incremental ? (uint64_t)sample * pixels + local
+                                 : (uint64_t)local * (uint64_t)p.spp + sample;
+    return c;
+}
+
 // camera.go:99-129
-RT_HD void camera_ray(const DevScene &s, const PassParams &p, int32_t x, int32_t y,
-                      uint64_t path_index, v3 &origin, v3 &dir) {
+RT_HD void camera_ray(const DevScene &s, const PassParams &p, const PathCtx &c, v3 &origin,
+                      v3 &dir) {
+    const int32_t x = c.x, y = c.y;
+    const uint64_t path_index = c.path_index;
     float jx = 0.5f, jy = 0.5f;
     if (s.n_cam > 0) {
         uint64_t k = path_index % (uint64_t)s.n_cam;
         jx = (float)s.cam_tab[2 * k];
         jy = (float)s.cam_tab[2 * k + 1];
     }
-    float lx = p.top_left[0] + p.steps[0] * ((float)(p.x_offset + x) + jx);
-    float ly = p.top_left[1] - p.steps[1] * ((float)(p.y_offset + y) + jy);
+    float lx = p.top_left[0] + p.steps[0] * ((float)(c.x_offset + x) + jx);
+    float ly = p.top_left[1] - p.steps[1] * ((float)(c.y_offset + y) + jy);
     origin = transform_coordinate(v3{lx, ly, -p.ppd}, p.cam_transform);
     v3 diff;
     if (p.projection == 0) {

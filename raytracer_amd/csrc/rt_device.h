@@ -42,6 +42,9 @@ struct Scene {
     // flattened buffers (HBM)
     rtc::f4 *d_nodes = nullptr;
     rtc::f4 *d_tris = nullptr;
+    rtc::f4 *d_pairs = nullptr;        // ordered-traversal records (fast mode), may be null
+    uint32_t fast_root = 0;
+    uint64_t pair_bytes = 0;
     int32_t *d_tri_mat = nullptr;
     float *d_kd = nullptr;
     float *d_tri_uv = nullptr;
@@ -64,6 +67,8 @@ struct Scene {
     int ws_L = 0, ws_B = 0;
     PathBuffers ws{};
     std::vector<void *> ws_allocs;
+    rtc::TileDesc *d_tiles = nullptr;   // tile table of a multi-tile call
+    size_t tile_cap = 0;
 };
 
 rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **out);
@@ -76,9 +81,10 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
                        hipStream_t stream);
 rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits, int mode,
                           bool want_counters, rt_stats *stats);
-rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sample_begin,
-                            int32_t sample_count, bool incremental, bool zero_accum,
-                            float *d_accum, uint8_t *d_rgba, rt_stats *stats, hipStream_t stream);
+rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
+                            int32_t sample_begin, int32_t sample_count, bool incremental,
+                            bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
+                            hipStream_t stream);
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
                            uint8_t *rgba, rt_stats *stats);
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,

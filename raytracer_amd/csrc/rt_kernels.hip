@@ -166,6 +166,151 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 }
 
 // ---------------------------------------------------------------------------
+// Traversal, fast mode: same box and triangle arithmetic, but the nearer child
+// is entered first and the farther one waits on a per-lane stack, so most of the
+// tree behind the first hit is never fetched.  The stack's top kStackLds entries
+// live in LDS ([entry][lane], 8 bytes each: child reference + entry distance),
+// deeper entries spill to scratch.  A popped entry whose entry distance is no
+// longer below the current hit distance is dropped without touching memory.
+// Results equal the reference-order traversal except where two candidates tie
+// exactly or the reference's own box test prunes a triangle it would accept.
+// ---------------------------------------------------------------------------
+constexpr int kStackLds = 16;
+constexpr int kStackSpill = 48;
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256)
+k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
+             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
+             unsigned long long *counters) {
+    __shared__ uint2 lds_stack[4 * kStackLds * 64];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t lane = lane_id();
+    uint2 *my_stack = lds_stack + (threadIdx.x >> 6) * (kStackLds * 64) + lane;
+    uint2 spill[kStackSpill];
+    int32_t idx = -1;
+    bool exhausted = false;
+    Ray<float> r;
+    Hit<float> h;
+    uint32_t cur = kRefDone;
+    int32_t sp = 0;
+    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
+
+    auto push = [&](uint32_t ref, float tn) {
+        const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
+        if (sp < kStackLds) my_stack[sp * 64] = e;
+        else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = e;
+        sp++;   // deeper than both levels cannot happen: trees deeper than 60 use the other kernel
+    };
+    // next entry that can still hold a closer hit, or kRefDone
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp--;
+            const uint2 e = sp < kStackLds ? my_stack[sp * 64] : spill[sp - kStackLds];
+            if (i2f((int32_t)e.y) < h.t) return e.x;
+        }
+        return kRefDone;
+    };
+
+    for (;;) {
+        uint64_t active = __ballot(idx >= 0);
+        if (!exhausted && __popcll(active) < kRefillBelow) {
+            const uint64_t idle = ~active;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const int leader = __ffsll((unsigned long long)idle) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(next, n_idle);
+            base = __shfl(base, leader);
+            if (idx < 0) {
+                const uint32_t mine = base + (uint32_t)__popcll(idle & lanemask_lt());
+                if (mine < n) {
+                    const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
+                    const f4 a = rp[0], b = rp[1];
+                    ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
+                    h.t = a.w;
+                    h.u = 0;
+                    h.v = 0;
+                    h.pos = -1;
+                    cur = s.fast_root;
+                    sp = 0;
+                    idx = (int32_t)mine;
+                }
+            }
+            if (base + n_idle >= n || base + n_idle < base) exhausted = true;
+            active = __ballot(idx >= 0);
+        }
+        if (active == 0) break;
+
+        // phase A: descend through interior records until a leaf (or nothing) is current
+        while (idx >= 0 && (cur & kLeafBit) == 0) {
+            const f4 *q = s.pairs + 4 * (size_t)cur;
+            const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (COUNT) { c_nodes++; c_box += 2; }
+            // slabs with the reference's arithmetic, (bound - origin) * invDir
+            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.w - r.ox) * r.ix;
+            const float ly0 = (q0.y - r.oy) * r.iy, ly1 = (q1.x - r.oy) * r.iy;
+            const float lz0 = (q0.z - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
+            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q2.y - r.ox) * r.ix;
+            const float ry0 = (q1.w - r.oy) * r.iy, ry1 = (q2.z - r.oy) * r.iy;
+            const float rz0 = (q2.x - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
+            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+            const bool hl = ln <= lf && ln < h.t && lf > 0;
+            const bool hr = rn <= rf && rn < h.t && rf > 0;
+            const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
+            if (hl && hr) {
+                const bool left_first = ln <= rn;
+                push(left_first ? rref : lref, left_first ? rn : ln);
+                cur = left_first ? lref : rref;
+            } else if (hl) {
+                cur = lref;
+            } else if (hr) {
+                cur = rref;
+            } else {
+                cur = pop();
+            }
+        }
+        // phase B: the current leaf's triangles
+        if (idx >= 0 && cur != kRefDone) {
+            const int32_t start = (int32_t)(cur & 0xFFFFFFu);
+            const int32_t count = (int32_t)((cur >> 24) & 0x7Fu);
+            for (int32_t k = 0; k < count; ++k) {
+                const f4 *q = s.tris + 3 * (size_t)(start + k);
+                const f4 q0 = q[0], q1 = q[1], q2 = q[2];
+                if (COUNT) c_fetch++;
+                const bool tested = tri_test<float, true>(r, q0, q1, q2, start + k, h);
+                if (COUNT && tested) c_test++;
+            }
+            cur = pop();
+        }
+        if (idx >= 0 && cur == kRefDone) {
+            f4 out;
+            out.x = i2f(h.pos);
+            out.y = h.t;
+            out.z = h.u;
+            out.w = h.v;
+            *reinterpret_cast<f4 *>(hits + idx) = out;
+            idx = -1;
+        }
+    }
+    if (COUNT) {
+        c_nodes = wave_sum(c_nodes);
+        c_box = wave_sum(c_box);
+        c_fetch = wave_sum(c_fetch);
+        c_test = wave_sum(c_test);
+        if (lane == 0) {
+            atomicAdd(counters + 1, (unsigned long long)c_nodes);
+            atomicAdd(counters + 2, (unsigned long long)c_box);
+            atomicAdd(counters + 3, (unsigned long long)c_fetch);
+            atomicAdd(counters + 4, (unsigned long long)c_test);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + 0, (unsigned long long)n);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Path-tracing wavefront kernels
 // ---------------------------------------------------------------------------
 enum : uint8_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
@@ -178,21 +323,15 @@ struct Batch {
     uint32_t n_samp;
 };
 
-__device__ __forceinline__ uint64_t path_index_of(const PassParams &p, uint32_t pix, uint32_t s) {
-    const uint64_t pixels = (uint64_t)p.width * (uint64_t)p.height;
-    return p.incremental ? (uint64_t)s * pixels + pix : (uint64_t)pix * (uint64_t)p.spp + s;
-}
-
 __global__ void __launch_bounds__(256)
 k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id == 0) w.counts[0] = b.P;
     if (id >= b.P) return;
     const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
-    const uint32_t pix = b.pix0 + pl, smp = b.s0 + sl;
-    const int32_t x = (int32_t)(pix % (uint32_t)p.width), y = (int32_t)(pix / (uint32_t)p.width);
+    const PathCtx ctx = locate_path(p, b.pix0 + pl, b.s0 + sl);
     v3 o, d;
-    camera_ray(s, p, x, y, path_index_of(p, pix, smp), o, d);
+    camera_ray(s, p, ctx, o, d);
     f4 *rp = reinterpret_cast<f4 *>(w.rays[0] + id);
     rp[0] = f4{o.x, o.y, o.z, kF32Max};
     rp[1] = f4{d.x, d.y, d.z, 0.0f};
@@ -278,7 +417,8 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         diffuse = material_diffuse(s, hit.tri_pos, hit.u, hit.v);
     }
     const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
-    const uint64_t stream = rng_stream(p.rng_seed, path_index_of(p, b.pix0 + pl, b.s0 + sl));
+    const PathCtx ctx = locate_path(p, b.pix0 + pl, b.s0 + sl);
+    const uint64_t stream = rng_stream(ctx.rng_seed, ctx.path_index);
     const uint64_t lbase = light_base(stream);
 
     // shadow rays of this vertex (the loop is uniform over the wave: L is a pass constant)
@@ -468,6 +608,11 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     if ((st = upload(&sc->d_mat_tex, sc->mat_tex.data(), sc->mat_tex.size() * 4)) != RT_OK) return st;
     sc->node_bytes = flat.nodes.size() * 4;
     sc->tri_bytes = flat.tris.size() * 4;
+    if (flat.fast_ok) {
+        if ((st = upload(&sc->d_pairs, flat.pairs.data(), flat.pairs.size() * 4)) != RT_OK) return st;
+        sc->fast_root = flat.fast_root;
+        sc->pair_bytes = flat.pairs.size() * 4;
+    }
     if ((st = upload(&sc->d_cursors, nullptr, kCursorSlots * sizeof(uint32_t))) != RT_OK) return st;
     HIP_TRY(hipMemset(sc->d_cursors, 0, kCursorSlots * sizeof(uint32_t)));
 
@@ -530,7 +675,7 @@ void scene_destroy(Scene *sc) {
     workspace_free(*sc);
     for (uint8_t *p : sc->tex_ptrs)
         if (p) (void)hipFree(p);
-    void *ptrs[] = {sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+    void *ptrs[] = {sc->d_pairs, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -553,6 +698,9 @@ static DevScene dev_view(const Scene &sc) {
     d.n_tris = sc.n_tris;
     d.n_cam = sc.n_cam;
     d.n_light = sc.n_light;
+    d.pairs = sc.d_pairs;
+    d.fast_root = sc.fast_root;
+    d.fast_ok = sc.d_pairs ? 1 : 0;
     return d;
 }
 
@@ -586,8 +734,17 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
     switch (mode) {
+    case RT_MODE_FAST_F32:
+        if (sc.d_pairs) {
+            if (d_counters)
+                hipLaunchKernelGGL((k_trace_fast<true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            else
+                hipLaunchKernelGGL((k_trace_fast<false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            break;
+        }
+        // trees that do not fit the ordered-traversal encoding run the reference order
+        [[fallthrough]];
     case RT_MODE_STRICT_F32:
-    case RT_MODE_FAST_F32:   // no reordered kernel yet: the fast mode runs the reference order
         if (d_counters)
             hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
         else
@@ -709,21 +866,46 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
     return RT_OK;
 }
 
-rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sample_begin,
-                            int32_t sample_count, bool incremental, bool zero_accum,
-                            float *d_accum, uint8_t *d_rgba, rt_stats *stats,
+// True when two passes differ only in what may differ between tiles of one frame.
+static bool same_frame(const rt_pass &a, const rt_pass &b) {
+    return std::memcmp(&a.camera, &b.camera, sizeof a.camera) == 0 &&
+           std::memcmp(&a.settings, &b.settings, sizeof a.settings) == 0 &&
+           a.total_width == b.total_width && a.total_height == b.total_height;
+}
+
+rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
+                            int32_t sample_begin, int32_t sample_count, bool incremental,
+                            bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
                             hipStream_t stream) {
     DeviceGuard guard(sc.device);
     if (stats) std::memset(stats, 0, sizeof *stats);
+    if (!passes || n_passes < 1) return fail(RT_ERR_INVALID, "no pass given");
+    if (n_passes > 65536) return fail(RT_ERR_INVALID, "more than 65536 tiles in one call");
     if (!d_accum) return fail(RT_ERR_INVALID, "accumulation buffer is NULL");
     if (sample_begin < 0 || sample_count < 0) return fail(RT_ERR_INVALID, "bad sample range");
     if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64)
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
+    const rt_pass &pass = passes[0];
     PassParams pp;
     rt_status st = prepare_pass(sc.light, pass, pp);
     if (st != RT_OK) return st;
     pp.incremental = incremental ? 1 : 0;
-    const size_t pixels = (size_t)pass.width * (size_t)pass.height;
+    size_t pixels = (size_t)pass.width * (size_t)pass.height;
+    std::vector<TileDesc> tiles;
+    if (n_passes > 1) {
+        tiles.resize((size_t)n_passes);
+        pixels = 0;
+        for (int32_t i = 0; i < n_passes; ++i) {
+            const rt_pass &t = passes[i];
+            if (!same_frame(pass, t))
+                return fail(RT_ERR_INVALID, "tiles of one call must share camera, settings and frame size (tile " + std::to_string(i) + ")");
+            if (t.width <= 0 || t.height <= 0)
+                return fail(RT_ERR_INVALID, "pass width/height must be positive (tile " + std::to_string(i) + ")");
+            tiles[(size_t)i] = TileDesc{t.x_offset, t.y_offset, t.width, t.height, t.rng_seed, (uint32_t)pixels, 0};
+            pixels += (size_t)t.width * (size_t)t.height;
+        }
+    }
+    if (pixels > 0xffffffffULL) return fail(RT_ERR_INVALID, "more than 2^32-1 pixels in one call");
     const int L = pp.L, B = pp.B;
 
     // batch shape: whole pixel rows of the tile-linear range x as many samples as fit
@@ -735,6 +917,19 @@ rt_status render_accumulate(Scene &sc, const rt_pass &pass, int mode, int32_t sa
     PathBuffers w;
     st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
     if (st != RT_OK) return st;
+    if (!tiles.empty()) {
+        if (sc.tile_cap < tiles.size()) {
+            if (sc.d_tiles) (void)hipFree(sc.d_tiles);
+            sc.d_tiles = nullptr;
+            sc.tile_cap = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc.d_tiles), tiles.size() * sizeof(TileDesc)));
+            sc.tile_cap = tiles.size();
+        }
+        HIP_TRY(hipMemcpyAsync(sc.d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // `tiles` is pageable host memory
+        pp.n_tiles = (int32_t)tiles.size();
+        pp.tiles = sc.d_tiles;
+    }
 
     const DevScene d = dev_view(sc);
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
@@ -854,7 +1049,7 @@ rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accu
         return fail(RT_ERR_NOMEM, "hipMalloc of the tile image failed");
     }
     rt_stats local;
-    rt_status st = render_accumulate(sc, pass, mode, 0, pass.camera.rays_per_pixel, false, true,
+    rt_status st = render_accumulate(sc, &pass, 1, mode, 0, pass.camera.rays_per_pixel, false, true,
                                      d_accum, d_rgba, stats ? stats : &local, nullptr);
     if (st == RT_OK) {
         hipError_t e = hipMemcpy(rgba, d_rgba, pixels * 4, hipMemcpyDeviceToHost);

@@ -52,6 +52,30 @@ void emul_trace(const float *nodes, int32_t n_nodes, const float *tris, int32_t 
     }
 }
 
+void emul_trace_fast(const float *pairs, uint32_t fast_root, const float *tris, int32_t n_tris,
+                     const EmulRay *rays, int64_t n, EmulHit *hits, uint64_t *counters) {
+    DevScene s{};
+    s.pairs = reinterpret_cast<const f4 *>(pairs);
+    s.fast_root = fast_root;
+    s.tris = reinterpret_cast<const f4 *>(tris);
+    s.n_tris = n_tris;
+    uint64_t tot[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        const EmulRay &r = rays[i];
+        Counters c;
+        Ray<float> ray;
+        ray_init(ray, r.o[0], r.o[1], r.o[2], r.dir[0], r.dir[1], r.dir[2]);
+        Hit<float> h{r.tmax, 0, 0, -1};
+        traverse_ordered<true>(s, ray, h, &c);
+        hits[i] = EmulHit{h.pos, h.t, h.u, h.v};
+        tot[0] += c.nodes_visited; tot[1] += c.box_tests; tot[2] += c.tris_fetched; tot[3] += c.tris_tested;
+    }
+    if (counters) {
+        counters[0] = (uint64_t)n;
+        for (int k = 0; k < 4; ++k) counters[1 + k] = tot[k];
+    }
+}
+
 // Serial path tracer over the device functions: the order of operations of
 // k_raygen / k_shade / k_finish / k_accumulate / k_resolve for one tile.
 void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t n_tris,
@@ -81,10 +105,10 @@ void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t
     std::vector<v3> shading, brdf;
     for (int64_t pix = 0; pix < pixels; ++pix) {
         for (int32_t sm = sample_begin; sm < sample_begin + sample_count; ++sm) {
-            const uint64_t path = p.incremental ? (uint64_t)sm * (uint64_t)pixels + (uint64_t)pix
-                                                : (uint64_t)pix * (uint64_t)p.spp + (uint64_t)sm;
+            const PathCtx ctx = locate_path(p, (uint32_t)pix, (uint32_t)sm);
+            const uint64_t path = ctx.path_index;
             v3 o, d;
-            camera_ray(s, p, (int32_t)(pix % p.width), (int32_t)(pix / p.width), path, o, d);
+            camera_ray(s, p, ctx, o, d);
             shading.clear(); brdf.clear();
             const uint64_t stream = rng_stream(p.rng_seed, path);
             const uint64_t lbase = light_base(stream);

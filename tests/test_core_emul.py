@@ -175,3 +175,59 @@ def test_default_sample_table_is_low_discrepancy(product_lib):
     assert len(cells) == 256
     assert abs(t.mean() - 0.5) < 0.01
     assert not np.array_equal(t, api.default_sample_table(4096, 6))
+
+
+def emul_trace_fast(emul, bvh, rays):
+    rec, root = bvh.flatten_ordered()
+    _, tris, _ = bvh.flatten()
+    hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
+    cnt = np.zeros(5, np.uint64)
+    emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
+                         tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                         rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
+                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+    return hits, cnt
+
+
+@pytest.mark.parametrize("n,leaf,depth", [(1, 6, 16), (34, 1, 8), (5000, 6, 24), (400, 200, 4),
+                                          (3000, 1, 12)])
+def test_ordered_traversal_finds_the_same_hits(product_lib, oracle, emul, n, leaf, depth):
+    """Fast mode: same closest hit as the reference order on generic rays (no
+    exact ties in a random soup), with far less work."""
+    sc = scenes.soup(n, seed=777 + n)
+    bvh = api.Bvh.build(product_mesh(sc), True, leaf, depth)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    rays = random_rays(8000, seed=5)
+    rays["tmax"][::4] = np.float32(1.5)
+    hits, cnt = emul_trace_fast(emul, bvh, rays)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax, counters=True)
+    diff = hits["tri_pos"] != ref["tri"]
+    assert diff.sum() == 0, int(diff.sum())
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(hits["u"].view(np.uint32), ref["u"].view(np.uint32))
+    if n >= 3000:
+        assert cnt[1] < ref["counters"]["nodes_visited"]
+
+
+def test_ordered_records_layout(product_lib):
+    sc = scenes.soup(300, seed=2)
+    bvh = api.Bvh.build(product_mesh(sc), True, 6, 16)
+    e = bvh.export()
+    rec, root = bvh.flatten_ordered()
+    assert root == 0 and rec.shape[0] == int((e["is_leaf"] == 0).sum())
+    refs = rec[:, 12:14].view(np.uint32)
+    leaf = (refs & 0x80000000) != 0
+    counts = (refs[leaf] >> 24) & 0x7F
+    starts = refs[leaf] & 0xFFFFFF
+    assert counts.sum() == 300 and sorted(starts.tolist()) == sorted(e["start"][e["is_leaf"] == 1].tolist())
+    assert np.all(refs[~leaf] < rec.shape[0])
+    # root record holds the boxes of nodes 1 and its sibling
+    assert np.array_equal(rec[0, 0:3], e["bmin"][1]) and np.array_equal(rec[0, 3:6], e["bmax"][1])
+    # oversized leaves are chained through synthetic records
+    big = api.Bvh.build(product_mesh(scenes.soup(500, seed=3)), False, 6, 16)
+    rec, root = big.flatten_ordered()
+    refs = rec[:, 12:14].view(np.uint32)
+    leaf = (refs & 0x80000000) != 0
+    assert (root & 0x80000000) == 0 and ((refs[leaf] >> 24) & 0x7F).sum() == 500
+    assert (((refs[leaf] >> 24) & 0x7F) <= 126).all()

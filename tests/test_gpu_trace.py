@@ -161,3 +161,85 @@ def test_scene_info_and_errors(soup20k, gpu_device):
         api.Scene(mesh, bvh, 999)
     with pytest.raises(api._capi.RtError):
         scene.trace_rays(random_rays(10, seed=1), mode=17)
+
+
+# ---------------------------------------------------------------------------
+# fast mode (ordered traversal): deterministic, equal to its lane-serial CPU
+# form bit for bit; equal to the reference order except for a counted handful
+# of rays where the reference's own box pruning rejects a triangle it accepts
+# ---------------------------------------------------------------------------
+def _emul_fast(emul, bvh, rays):
+    import ctypes as C
+    rec, root = bvh.flatten_ordered()
+    _, tris, _ = bvh.flatten()
+    hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
+    cnt = np.zeros(5, np.uint64)
+    emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
+                         tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                         rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
+                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+    return hits, cnt
+
+
+def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul):
+    _, _, bvh, scene, osc = soup20k
+    rays = random_rays(300000, seed=9)
+    rays["tmax"][::7] = np.float32(0.9)
+    hits, st = scene.trace_rays(rays, mode=api.MODE_FAST_F32, counters=True)
+    cpu, cnt = _emul_fast(emul, bvh, rays)
+    assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
+    assert [st["rays"], st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]] == cnt.tolist()
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax, counters=True)
+    mismatch = int((hits["tri_pos"] != ref["tri"]).sum())
+    assert mismatch <= 3, mismatch
+    same = hits["tri_pos"] == ref["tri"]
+    assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
+    assert st["nodes_visited"] < 0.7 * ref["counters"]["nodes_visited"]
+
+
+def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
+    """Rays along quad diagonals and box faces: exact t ties between the two
+    triangles of a wall resolve to the earlier array position, as in the
+    reference order."""
+    sc = scenes.room_mesh(48, seed=5, total=6000)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 4, 40)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    cam = sc["camera"]
+    o, d = scenes.primary_rays(320, 180, cam)
+    extra_o, extra_d = [], []
+    for k in range(2000):           # rays aimed exactly at wall diagonals
+        s = k / 2000.0
+        extra_o.append([0.0, 1.0, 0.0])
+        tgt = np.array([-1.38 + 2.76 * s, 1.08 * s, -1.38], np.float32)
+        v = tgt - np.float32([0.0, 1.0, 0.0])
+        extra_d.append(v / np.linalg.norm(v))
+    rays = np.concatenate([api.make_rays(o, d),
+                           api.make_rays(np.array(extra_o, np.float32), np.array(extra_d, np.float32)),
+                           random_rays(100000, seed=2, extent=1.0)])
+    hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax)
+    mismatch = int((hits["tri_pos"] != ref["tri"]).sum())
+    assert mismatch <= 1e-4 * len(rays), mismatch
+    same = (hits["tri_pos"] == ref["tri"])
+    assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
+    assert (hits["tri_pos"] >= 0).mean() > 0.5
+
+
+def test_fast_mode_deep_and_degenerate_trees(product_lib, oracle, gpu_device):
+    for n, use_bvh, leaf, depth in [(1, True, 6, 16), (300, False, 6, 16), (4000, True, 1, 40),
+                                    (4000, True, 6, 2)]:
+        sc = scenes.soup(n, seed=50 + n + depth, extent=0.5, size=0.1)
+        mesh = product_mesh(sc)
+        bvh = api.Bvh.build(mesh, use_bvh, leaf, depth)
+        scene = api.Scene(mesh, bvh, gpu_device)
+        osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+        rays = random_rays(20000, seed=n, extent=1.0)
+        hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
+        r6, tmax = rays6(rays)
+        ref = osc.trace_rays(r6, tmax)
+        assert int((hits["tri_pos"] != ref["tri"]).sum()) <= 2
+        assert (hits["tri_pos"] >= 0).sum() > 0
