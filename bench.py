@@ -60,6 +60,8 @@ def parse_args():
                     help="budget of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
+    ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
     return ap.parse_args()
 
 
@@ -143,6 +145,10 @@ def main():
     bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
     scene = api.Scene(mesh, bvh, local_rank)
     setup_s = time.perf_counter() - t0
+    if args.tune:
+        scene.set_tuning(*[int(x) for x in args.tune.split(",")])
+    if args.max_paths:
+        scene.set_max_paths(args.max_paths)
     tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
 
     tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])

@@ -166,6 +166,12 @@ rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_
 /* Upper bound on camera samples traced together by the tile renderer (sets
  * the size of its device workspace); default 4194304. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
+/* Launch parameters of the traversal kernels, for experiments: entries of the
+ * per-lane stack kept in LDS (8, 12, 16 or 24; deeper entries spill), the
+ * active-lane count below which a wave refills its idle lanes (1..64), and
+ * persistent blocks per CU.  Results do not depend on them. */
+rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
+                              int32_t blocks_per_cu);
 /* When enabled, render calls that return rt_stats run the counting variant of
  * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
  * tris_tested (slower; for the roofline byte model, not for timed runs). */

@@ -202,6 +202,19 @@ rt_status rt_scene_set_counters(rt_scene *scene, int32_t enabled) {
     return RT_OK;
 }
 
+rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
+                              int32_t blocks_per_cu) {
+    if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (stack_entries != 8 && stack_entries != 12 && stack_entries != 16 && stack_entries != 24)
+        return fail(RT_ERR_INVALID, "stack_entries must be 8, 12, 16 or 24");
+    if (refill_below < 1 || refill_below > 64 || blocks_per_cu < 1 || blocks_per_cu > 64)
+        return fail(RT_ERR_INVALID, "tuning value out of range");
+    scene->impl->tune_stack = stack_entries;
+    scene->impl->tune_refill = refill_below;
+    scene->impl->tune_blocks_per_cu = blocks_per_cu;
+    return RT_OK;
+}
+
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (max_paths < 64 || max_paths > ((uint64_t)1 << 28))

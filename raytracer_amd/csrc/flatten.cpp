@@ -15,12 +15,12 @@ namespace {
 // Child-pair records for the ordered traversal.  Leaves larger than the 7-bit
 // count field are cut into a chain of synthetic interior records that reuse the
 // leaf's box; an empty leaf (the reference can create one, bvh.go:94-100 with
-// BVHMaxLeafSize 1) gets an inverted box that no ray enters.
+// BVHMaxLeafSize 1) gets NaN bounds that no ray enters.
 struct PairBuilder {
     const Bvh &bvh;
     const std::vector<int32_t> &skip;
     std::vector<float> &pairs;
-    const float inf;
+    const float nan_;
 
     uint32_t new_record() {
         pairs.resize(pairs.size() + 16, 0.0f);
@@ -54,7 +54,8 @@ struct PairBuilder {
         const int32_t start = bvh.start[(size_t)node];
         const int32_t count = bvh.end[(size_t)node] - start + 1;
         if (count <= 0) {
-            for (int k = 0; k < 3; ++k) { mn[k] = inf; mx[k] = -inf; }
+            // NaN bounds fail every comparison of the slab test
+            for (int k = 0; k < 3; ++k) { mn[k] = nan_; mx[k] = nan_; }
             return rtc::kLeafBit;   // count 0
         }
         return leaf_ref(start, count, mn, mx);
@@ -67,7 +68,7 @@ void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t>
     out.fast_ok = false;
     out.fast_root = 0;
     if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
-    PairBuilder b{bvh, skip, out.pairs, std::numeric_limits<float>::infinity(), {}};
+    PairBuilder b{bvh, skip, out.pairs, std::numeric_limits<float>::quiet_NaN(), {}};
     const int32_t nn = bvh.n_nodes;
     b.record_of.assign((size_t)nn, 0);
     for (int32_t i = 0; i < nn; ++i)

@@ -24,6 +24,7 @@ struct PathBuffers {
     uint8_t *n_terms;
     float *cur_dir;            // P*3
     uint32_t *rng_ctr;
+    uint64_t *rng_stream;      // per path: counter-RNG stream key
     int32_t *bounce_q;
     int32_t *shadow_q;         // P*L
     float *shadow_col;         // P*L*3
@@ -62,6 +63,10 @@ struct Scene {
     std::vector<int32_t> tex_dims;
     // path-tracing workspace (grow-only)
     size_t max_paths_in_flight = (size_t)1 << 22;
+    // launch tuning (defaults chosen by measurement; overridable for experiments)
+    int tune_stack = 8;           // LDS stack entries per lane of the fast kernel
+    int tune_refill = 48;         // refill idle lanes once fewer than this many are active
+    int tune_blocks_per_cu = 8;   // persistent grid size
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;

@@ -172,17 +172,21 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // live in LDS ([entry][lane], 8 bytes each: child reference + entry distance),
 // deeper entries spill to scratch.  A popped entry whose entry distance is no
 // longer below the current hit distance is dropped without touching memory.
-// Results equal the reference-order traversal except where two candidates tie
-// exactly or the reference's own box test prunes a triangle it would accept.
+//
+// The loop alternates two phases, "descend through interior records until this
+// lane holds a leaf" and "test the leaf's triangles", so that the lanes of a
+// wave run the same code most of the time.  Results equal the reference-order
+// traversal except where the reference's own box test prunes a triangle it
+// would accept.
 // ---------------------------------------------------------------------------
-constexpr int kStackLds = 16;
-constexpr int kStackSpill = 48;
+constexpr int kStackTotal = 64;
 
-template <bool COUNT>
+template <bool COUNT, int kStackLds>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters) {
+             unsigned long long *counters, int refill_below) {
+    constexpr int kStackSpill = kStackTotal - kStackLds;
     __shared__ uint2 lds_stack[4 * kStackLds * 64];
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t lane = lane_id();
@@ -192,29 +196,52 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     bool exhausted = false;
     Ray<float> r;
     Hit<float> h;
-    uint32_t cur = kRefDone;
+    uint32_t cur = 0;            // interior record when tri_n == 0
+    int32_t tri_i = 0, tri_n = 0;   // next triangle and how many remain in the current leaf
     int32_t sp = 0;
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
 
     auto push = [&](uint32_t ref, float tn) {
         const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
         if (sp < kStackLds) my_stack[sp * 64] = e;
-        else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = e;
+        else if (sp < kStackTotal) spill[sp - kStackLds] = e;
         sp++;   // deeper than both levels cannot happen: trees deeper than 60 use the other kernel
     };
-    // next entry that can still hold a closer hit, or kRefDone
-    auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
-            sp--;
-            const uint2 e = sp < kStackLds ? my_stack[sp * 64] : spill[sp - kStackLds];
-            if (i2f((int32_t)e.y) < h.t) return e.x;
+    // Moves the lane to `ref`, or to the next stacked entry that can still hold
+    // a closer hit; returns false when the ray is finished.
+    auto enter = [&](uint32_t ref) -> bool {
+        for (;;) {
+            if (ref != kRefDone) {
+                if ((ref & kLeafBit) == 0) {
+                    cur = ref;
+                    tri_n = 0;
+                    return true;
+                }
+                const int32_t count = (int32_t)((ref >> 24) & 0x7Fu);
+                if (count > 0) {
+                    tri_i = (int32_t)(ref & 0xFFFFFFu);
+                    tri_n = count;
+                    return true;
+                }
+            }
+            ref = kRefDone;
+            while (sp > 0) {
+                sp--;
+                uint2 e;
+                if (sp < kStackLds) e = my_stack[sp * 64];
+                else e = spill[sp - kStackLds];
+                if (i2f((int32_t)e.y) < h.t) {
+                    ref = e.x;
+                    break;
+                }
+            }
+            if (ref == kRefDone) return false;
         }
-        return kRefDone;
     };
 
     for (;;) {
         uint64_t active = __ballot(idx >= 0);
-        if (!exhausted && __popcll(active) < kRefillBelow) {
+        if (!exhausted && (int)__popcll(active) < refill_below) {
             const uint64_t idle = ~active;
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const int leader = __ffsll((unsigned long long)idle) - 1;
@@ -231,9 +258,12 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                     h.u = 0;
                     h.v = 0;
                     h.pos = -1;
-                    cur = s.fast_root;
                     sp = 0;
                     idx = (int32_t)mine;
+                    if (!enter(s.fast_root)) {   // cannot happen for a non-empty scene
+                        *reinterpret_cast<f4 *>(hits + idx) = f4{i2f(-1), h.t, 0.0f, 0.0f};
+                        idx = -1;
+                    }
                 }
             }
             if (base + n_idle >= n || base + n_idle < base) exhausted = true;
@@ -241,8 +271,10 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         }
         if (active == 0) break;
 
-        // phase A: descend through interior records until a leaf (or nothing) is current
-        while (idx >= 0 && (cur & kLeafBit) == 0) {
+        // phase A: lanes standing on an interior record descend until they reach a
+        // leaf or run out of work
+        bool alive = true;
+        while (idx >= 0 && alive && tri_n == 0) {
             const f4 *q = s.pairs + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c_nodes++; c_box += 2; }
@@ -260,32 +292,39 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool hl = ln <= lf && ln < h.t && lf > 0;
             const bool hr = rn <= rf && rn < h.t && rf > 0;
             const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
+            uint32_t nxt = kRefDone;
             if (hl && hr) {
                 const bool left_first = ln <= rn;
                 push(left_first ? rref : lref, left_first ? rn : ln);
-                cur = left_first ? lref : rref;
+                nxt = left_first ? lref : rref;
             } else if (hl) {
-                cur = lref;
+                nxt = lref;
             } else if (hr) {
-                cur = rref;
-            } else {
-                cur = pop();
+                nxt = rref;
             }
+            alive = enter(nxt);
         }
-        // phase B: the current leaf's triangles
-        if (idx >= 0 && cur != kRefDone) {
-            const int32_t start = (int32_t)(cur & 0xFFFFFFu);
-            const int32_t count = (int32_t)((cur >> 24) & 0x7Fu);
-            for (int32_t k = 0; k < count; ++k) {
-                const f4 *q = s.tris + 3 * (size_t)(start + k);
-                const f4 q0 = q[0], q1 = q[1], q2 = q[2];
-                if (COUNT) c_fetch++;
-                const bool tested = tri_test<float, true>(r, q0, q1, q2, start + k, h);
+        // phase B: the leaf's triangles in array order, two fetched at a time so
+        // that their loads overlap
+        if (idx >= 0 && alive && tri_n > 0) {
+            for (; tri_n > 0; tri_i += 2, tri_n -= 2) {
+                const bool two = tri_n > 1;
+                const f4 *qa = s.tris + 3 * (size_t)tri_i;
+                const f4 *qb = qa + (two ? 3 : 0);
+                const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
+                const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
+                if (COUNT) c_fetch += two ? 2 : 1;
+                bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
                 if (COUNT && tested) c_test++;
+                if (two) {
+                    tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
+                    if (COUNT && tested) c_test++;
+                }
             }
-            cur = pop();
+            tri_n = 0;
+            alive = enter(kRefDone);
         }
-        if (idx >= 0 && cur == kRefDone) {
+        if (idx >= 0 && !alive) {
             f4 out;
             out.x = i2f(h.pos);
             out.y = h.t;
@@ -338,6 +377,7 @@ k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
     w.state[id] = kActive;
     w.n_terms[id] = 0;
     w.rng_ctr[id] = 0;
+    w.rng_stream[id] = rng_stream(ctx.rng_seed, ctx.path_index);
     w.cur_dir[3 * (size_t)id + 0] = d.x;
     w.cur_dir[3 * (size_t)id + 1] = d.y;
     w.cur_dir[3 * (size_t)id + 2] = d.z;
@@ -416,9 +456,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         normal = v3{q0.x, q0.y, q0.z};
         diffuse = material_diffuse(s, hit.tri_pos, hit.u, hit.v);
     }
-    const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
-    const PathCtx ctx = locate_path(p, b.pix0 + pl, b.s0 + sl);
-    const uint64_t stream = rng_stream(ctx.rng_seed, ctx.path_index);
+    const uint64_t stream = at_vertex ? w.rng_stream[id] : 0;
     const uint64_t lbase = light_base(stream);
 
     // shadow rays of this vertex (the loop is uniform over the wave: L is a pass constant)
@@ -712,7 +750,7 @@ static DevScene dev_view(const Scene &sc) {
 // occupancy, never more blocks than there are 64-ray chunks.
 static uint32_t trace_grid(const Scene &sc, size_t n) {
     const size_t chunks = (n + 255) / 256;
-    size_t blocks = (size_t)sc.num_cus * 8;
+    size_t blocks = (size_t)sc.num_cus * (size_t)sc.tune_blocks_per_cu;
     if (blocks > chunks) blocks = chunks;
     if (blocks == 0) blocks = 1;
     return (uint32_t)blocks;
@@ -736,10 +774,17 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     switch (mode) {
     case RT_MODE_FAST_F32:
         if (sc.d_pairs) {
-            if (d_counters)
-                hipLaunchKernelGGL((k_trace_fast<true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
-            else
-                hipLaunchKernelGGL((k_trace_fast<false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            const int rb = sc.tune_refill;
+            if (d_counters) {
+                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb);
+            } else {
+                switch (sc.tune_stack) {
+                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
+                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
+                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
+                }
+            }
             break;
         }
         // trees that do not fit the ordered-traversal encoding run the reference order
@@ -850,6 +895,7 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.cur_dir), P * 12));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
+        HIP_TRY(alloc(reinterpret_cast<void **>(&b.rng_stream), P * 8));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
         HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
