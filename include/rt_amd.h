@@ -159,6 +159,11 @@ rt_status rt_scene_set_sample_tables(rt_scene *scene, const double *camera_tab,
                                      int32_t n_light);
 /* Build-defined scrambled Halton (bases 2, 3) table: out[n*2]. */
 rt_status rt_default_sample_table(int32_t n, uint64_t seed, double *out);
+/* PNG bytes -> RGBA8 rows as NewTexture holds them (models/texture.go:24-46):
+ * opaque images unchanged, images with alpha premultiplied the way image/draw
+ * converts NRGBA to RGBA.  Call with rgba == NULL to get the size. */
+rt_status rt_png_decode(const uint8_t *data, size_t size, uint8_t *rgba, size_t capacity,
+                        int32_t *width, int32_t *height);
 /* Texture for material lookups (models/texture.go:24-59): RGBA8 rows, top
  * row first, as image.RGBA stores them. */
 rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_t *rgba,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "rt_scene_light": (C.c_int32, [vp, C.POINTER(Light)]),
     "rt_scene_set_sample_tables": (C.c_int32, [vp, vp, C.c_int32, vp, C.c_int32]),
     "rt_default_sample_table": (C.c_int32, [C.c_int32, C.c_uint64, vp]),
+    "rt_png_decode": (C.c_int32, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]),
     "rt_scene_set_texture": (C.c_int32, [vp, C.c_int32, vp, C.c_int32, C.c_int32]),
     "rt_scene_set_max_paths": (C.c_int32, [vp, C.c_uint64]),
     "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32]),

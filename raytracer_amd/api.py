@@ -158,6 +158,16 @@ def default_sample_table(n, seed):
     return out
 
 
+def png_decode(data):
+    """PNG bytes -> (h, w, 4) uint8 RGBA (premultiplied where the file has alpha)."""
+    raw = bytes(data)
+    w, h = C.c_int32(), C.c_int32()
+    check(lib().rt_png_decode(raw, len(raw), None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    check(lib().rt_png_decode(raw, len(raw), _ptr(out), out.size, C.byref(w), C.byref(h)))
+    return out
+
+
 def camera_setup(cam, total_w, total_h):
     tl = np.zeros(3, np.float32)
     st = np.zeros(2, np.float32)

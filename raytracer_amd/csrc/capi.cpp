@@ -6,6 +6,7 @@
 #include <new>
 #include <string>
 
+#include "backend.h"
 #include "rt_device.h"
 #include "rt_internal.h"
 
@@ -275,6 +276,21 @@ rt_status rt_default_sample_table(int32_t n, uint64_t seed, double *out) {
     RT_GUARD_BEGIN
     if (n < 0 || (n > 0 && !out)) return fail(RT_ERR_INVALID, "bad table arguments");
     rt::default_sample_table(n, seed, out);
+    return RT_OK;
+    RT_GUARD_END
+}
+
+rt_status rt_png_decode(const uint8_t *data, size_t size, uint8_t *rgba, size_t capacity,
+                        int32_t *width, int32_t *height) {
+    RT_GUARD_BEGIN
+    if (!data || !width || !height) return fail(RT_ERR_INVALID, "NULL argument");
+    std::vector<uint8_t> px;
+    rt_status st = rt::decode_png(data, size, px, *width, *height);
+    if (st != RT_OK) return st;
+    if (rgba) {
+        if (capacity < px.size()) return fail(RT_ERR_INVALID, "pixel buffer too small");
+        std::memcpy(rgba, px.data(), px.size());
+    }
     return RT_OK;
     RT_GUARD_END
 }
