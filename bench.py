@@ -60,6 +60,12 @@ def parse_args():
                     help="budget of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (tiles staged through host memory, all ranks may "
+                         "share one GPU) is for rehearsing the multi-rank path on a 1-GPU box")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="ranks pull tiles from a shared counter instead of the static block-cyclic deal")
+    ap.add_argument("--chunk", type=int, default=8, help="tiles taken per pull with --dynamic")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
     ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
     return ap.parse_args()
@@ -122,7 +128,7 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from raytracer_amd import api, scenes
+    from raytracer_amd import api, scenes, tiles
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,9 +137,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     wl = WORKLOADS[args.workload]
     mode = {"strict": api.MODE_STRICT_F32, "fast": api.MODE_FAST_F32, "fp64": api.MODE_FP64}[args.mode]
@@ -152,18 +164,22 @@ def main():
     tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
 
     tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
-    my_tiles = [t for i, t in enumerate(tile_list) if i % world == rank]
+    my_tiles = [tile_list[i] for i in tiles.static_assignment(len(tile_list), world, rank)]
     # every rank's tile images live back to back in one buffer; ranks own equal
     # numbers of pixels only when the tile grid divides evenly, so pad to the maximum
-    px_of = [sum(t[3] * t[4] for i, t in enumerate(tile_list) if i % world == r) for r in range(world)]
+    px_of = [sum(t[3] * t[4] for t in tile_list[r::world]) for r in range(world)]
     my_px, max_px = px_of[rank], max(px_of)
+    if args.dynamic:
+        my_px = max_px = sum(t[3] * t[4] for t in tile_list)   # a rank may end up with any tile
     stream = torch.cuda.current_stream().cuda_stream
     d_accum = torch.empty((max(my_px, 1) * 3,), dtype=torch.float32, device="cuda")
     d_tiles = torch.zeros((max_px * 4,), dtype=torch.uint8, device="cuda")
-    gather_list = None
-    if world > 1 and rank == 0 and not args.no_gather:
-        gather_list = [torch.empty_like(d_tiles) for _ in range(world)]
-    frame = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+    frame = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8, device="cuda")
+    frame_host = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8) if coll_dev == "cpu" else None
+    queue = None
+    if args.dynamic and world > 1:
+        queue = tiles.TileQueue(dist.distributed_c10d._get_default_store(), len(tile_list),
+                                chunk=args.chunk)
 
     def make_pass(tile, spp, seed):
         tid, x, y, w, h = tile
@@ -172,22 +188,41 @@ def main():
             light_samples=wl["light_samples"], intensity=wl["intensity"], seed=seed,
             x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid))
 
+    def render_tiles(group, step):
+        """One call for a whole group of tiles: one ray queue per path depth for
+        the group, so small tiles still fill the GPU."""
+        passes = [make_pass(t, args.spp, 1 + 1000 * step) for t in group]
+        return scene.render_tiles_device(passes, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
+                                         stream=stream, want_stats=True)
+
     def run_step(step, collect):
-        # all of this rank's tiles in one call: one ray queue per path depth for the
-        # whole tile set, so small tiles still fill the GPU
-        passes = [make_pass(tile, args.spp, 1 + 1000 * step) for tile in my_tiles]
-        st = scene.render_tiles_device(passes, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
-                                       stream=stream, want_stats=True)
-        rays, kernel_ms = st["rays"], st["kernel_ms"]
-        if world > 1 and not args.no_gather:
-            dist.gather(d_tiles, gather_list, dst=0)
-        if rank == 0:
-            srcs = gather_list if gather_list is not None else [d_tiles]
-            for r, buf in enumerate(srcs):
+        rays, kernel_ms = 0, 0.0
+        if queue is None:
+            st = render_tiles(my_tiles, step)
+            rays, kernel_ms = st["rays"], st["kernel_ms"]
+            if not args.no_gather:
+                if coll_dev == "cuda":
+                    tiles.gather_static(d_tiles, tile_list, world, rank, frame)
+                else:
+                    tiles.gather_static(d_tiles.cpu(), tile_list, world, rank, frame_host)
+        else:
+            # pull-based: take the next chunk of tiles until the list is empty
+            queue.reset(epoch=step)
+            frame.zero_()
+            while True:
+                got = queue.pull()
+                if not got:
+                    break
+                group = [tile_list[i] for i in got]
+                st = render_tiles(group, step)
+                rays += st["rays"]
+                kernel_ms += st["kernel_ms"]
                 off = 0
-                for (tid, x, y, w, h) in tile_list[r::world]:
-                    frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
+                for (tid, x, y, w, h) in group:
+                    frame[y:y + h, x:x + w] = d_tiles[off:off + w * h * 4].view(h, w, 4)
                     off += w * h * 4
+            if not args.no_gather:
+                tiles.reduce_dynamic(frame if coll_dev == "cuda" else frame.cpu(), world, rank)
         if collect:
             collect["rays"] += rays
             collect["kernel_ms"] += kernel_ms
@@ -218,7 +253,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(acc["rays"]), elapsed, acc["kernel_ms"]], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(acc["rays"]), elapsed, acc["kernel_ms"]], dtype=torch.float64, device=coll_dev)
     if world > 1:
         t_max = tot.clone()
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -250,7 +285,8 @@ def main():
                        "triangles": int(mesh.n_tris), "bvh_nodes": int(bvh.n_nodes),
                        "width": wl["width"], "height": wl["height"], "spp": args.spp,
                        "bounces": wl["bounces"], "light_samples": wl["light_samples"],
-                       "tiles": len(tile_list), "tile_assignment": "block-cyclic",
+                       "tiles": len(tile_list),
+                       "tile_assignment": "dynamic pull queue" if queue is not None else "block-cyclic",
                        "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
                        "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "kernel": {"fast": "k_trace_fast", "strict": "k_trace_ref<float>",

@@ -1,0 +1,89 @@
+"""Tile sharding of one frame over the ranks of a node and the exchange step
+that brings the finished tiles to rank 0.
+
+The reference distributes a frame the same way over browser workers: the scene
+and BVH are copied to every worker (frontend Renderer.js:213-228,281-297), the
+frame is cut into a grid of tiles (Renderer.js:388-405), every finished worker
+takes the next tile from a shared list (Renderer.js:565-568) and the page
+composites the returned tiles by offset (RendererFrame.js:79-105).  Here a rank
+is one process with one GPU; the tile list is dealt either statically
+(block-cyclic) or through a shared counter that ranks pull from, and the tiles
+come home through one collective (RCCL on GPUs, gloo on CPU tensors in tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def static_assignment(n_tiles, world, rank):
+    """Block-cyclic: tile i belongs to rank i % world."""
+    return list(range(rank, n_tiles, world))
+
+
+class TileQueue:
+    """Pull-based tile list shared by all ranks: the counterpart of the
+    frontend's `renderTasks.pop()`.  Backed by the process group's key-value
+    store (an atomic add on the store's host), so a rank that finishes early
+    simply takes more tiles.  `chunk` tiles are taken per pull."""
+
+    def __init__(self, store, n_tiles, chunk=1, key="rt_tile_cursor"):
+        self.store, self.n_tiles, self.chunk, self.key = store, n_tiles, max(1, int(chunk)), key
+
+    def reset(self, epoch):
+        """Every rank calls this with the same epoch before a frame."""
+        self.key_epoch = f"{self.key}_{epoch}"
+
+    def pull(self):
+        """Next chunk of tile indices, [] when the list is exhausted."""
+        end = self.store.add(self.key_epoch, self.chunk)
+        start = end - self.chunk
+        return list(range(start, min(end, self.n_tiles))) if start < self.n_tiles else []
+
+
+def tile_pixel_offsets(tiles):
+    """Start pixel of every tile when a rank's tiles are stored back to back."""
+    offs, total = [], 0
+    for (_tid, _x, _y, w, h) in tiles:
+        offs.append(total)
+        total += w * h
+    return offs, total
+
+
+def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None):
+    """Static assignment: every rank holds the RGBA8 images of its block-cyclic
+    tiles back to back in `local_rgba` (uint8, padded to the largest per-rank
+    size).  One gather to rank 0, which pastes every tile at its offset into
+    `frame` ((H, W, 4) uint8).  Returns the frame on rank 0, None elsewhere."""
+    if world > 1:
+        bufs = [torch.empty_like(local_rgba) for _ in range(world)] if rank == 0 else None
+        dist.gather(local_rgba, bufs, dst=0, group=group)
+    else:
+        bufs = [local_rgba]
+    if rank != 0:
+        return None
+    for r, buf in enumerate(bufs):
+        off = 0
+        for (_tid, x, y, w, h) in tile_list[r::world]:
+            frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
+            off += w * h * 4
+    return frame
+
+
+def reduce_dynamic(local_frame, world, rank, group=None):
+    """Dynamic assignment: each rank pasted the tiles it happened to render into
+    its own zero-initialised full-size frame; tiles are disjoint, so a sum over
+    ranks is the composite.  Returns the frame on rank 0."""
+    if world > 1:
+        # widen so that the sum cannot overflow where a backend reduces in the tensor's dtype
+        wide = local_frame.to(torch.int32)
+        dist.reduce(wide, dst=0, op=dist.ReduceOp.SUM, group=group)
+        return wide.to(torch.uint8) if rank == 0 else None
+    return local_frame
+
+
+def sum_counters(values, device, world, group=None):
+    """All-reduce of scalar counters (the frontend sums the workers' ray
+    counters, Renderer.js:772-774).  Returns Python ints."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [int(round(v)) for v in t.tolist()]
