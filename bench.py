@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=8, help="samples per pixel of one frame")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel of one frame")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["strict", "fast", "fp64"],
                     help="traversal kernel: fast = ordered traversal (default), strict = the "
