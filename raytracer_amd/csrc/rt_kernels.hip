@@ -56,9 +56,70 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
     return base + (uint32_t)__popcll(m & lanemask_lt());
 }
 
+// Block-aggregated queue append: ONE atomic per workgroup, slots in thread
+// order.  Every thread of the block must call it, the same number of times;
+// `call` is that running count (alternates the LDS slot so consecutive calls
+// need no third barrier).
+constexpr int kShadeBlock = 512;
+__device__ __forceinline__ uint32_t block_append(uint32_t *counter, bool want, int call) {
+    __shared__ uint32_t s_cnt[2][kShadeBlock / 64];
+    __shared__ uint32_t s_base[2];
+    const int slot = call & 1;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t m = __ballot(want);
+    if (lane_id() == 0) s_cnt[slot][wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < blockDim.x / 64; ++i) total += s_cnt[slot][i];
+        s_base[slot] = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    uint32_t base = s_base[slot];
+    for (uint32_t i = 0; i < wave; ++i) base += s_cnt[slot][i];
+    return base + (uint32_t)__popcll(m & lanemask_lt());
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// Ray hand-out for the persistent traversal waves.  A returning atomic on one
+// word completes every ~11 ns chip-wide, so a wave must not take rays a few at
+// a time from the global cursor: it reserves a chunk of kRayChunk consecutive
+// rays with one atomic, keeps the chunk's bounds in scalar registers and fills
+// its idle lanes from it without touching memory again until it runs dry.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRayChunk = 256;
+
+struct RayFeed {
+    uint32_t pos = 0, end = 0;   // wave-uniform: the reserved chunk [pos, end)
+    bool exhausted = false;      // the global cursor has passed the last ray
+};
+
+// Called by all lanes of the wave.  `idle` = ballot of lanes without a ray.
+// Returns this lane's new ray index, or -1.
+__device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint32_t n, uint64_t idle) {
+    if (f.pos >= f.end && !f.exhausted) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(cursor, kRayChunk);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) {
+            f.exhausted = true;
+        } else {
+            f.pos = base;
+            f.end = (n - base < kRayChunk) ? n : base + kRayChunk;
+        }
+    }
+    const uint32_t avail = f.end - f.pos;
+    const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+    const bool is_idle = (idle >> lane_id()) & 1ull;
+    const int32_t mine = (is_idle && rank < avail) ? (int32_t)(f.pos + rank) : -1;
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    f.pos += n_idle < avail ? n_idle : avail;
+    return mine;
 }
 
 // ---------------------------------------------------------------------------
@@ -73,7 +134,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             unsigned long long *counters) {
     const uint32_t n = n_dev ? *n_dev : n_host;
     int32_t idx = -1;            // ray owned by this lane, -1 = idle
-    bool exhausted = false;      // wave-uniform: the cursor has passed n
+    RayFeed feed;
     Ray<Real> r;
     Hit<Real> h;
     int32_t node = 0, leaf_a = 0, leaf_n = 0;
@@ -81,32 +142,26 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 
     for (;;) {
         uint64_t active = __ballot(idx >= 0);
-        if (!exhausted && __popcll(active) < kRefillBelow) {
-            const uint64_t idle = ~active;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const int leader = __ffsll((unsigned long long)idle) - 1;
-            uint32_t base = 0;
-            if ((int)lane_id() == leader) base = atomicAdd(next, n_idle);
-            base = __shfl(base, leader);
-            if (idx < 0) {
-                const uint32_t mine = base + (uint32_t)__popcll(idle & lanemask_lt());
-                if (mine < n) {
-                    const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
-                    const f4 a = rp[0], b = rp[1];
-                    ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
-                    h.t = (Real)a.w;
-                    h.u = 0;
-                    h.v = 0;
-                    h.pos = -1;
-                    node = 0;
-                    leaf_n = 0;
-                    idx = (int32_t)mine;
-                }
+        if (!(feed.exhausted && feed.pos >= feed.end) && __popcll(active) < kRefillBelow) {
+            const int32_t mine = feed_take(feed, next, n, ~active);
+            if (mine >= 0) {
+                const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
+                const f4 a = rp[0], b = rp[1];
+                ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
+                h.t = (Real)a.w;
+                h.u = 0;
+                h.v = 0;
+                h.pos = -1;
+                node = 0;
+                leaf_n = 0;
+                idx = mine;
             }
-            if (base + n_idle >= n || base + n_idle < base) exhausted = true;
             active = __ballot(idx >= 0);
         }
-        if (active == 0) break;
+        if (active == 0) {
+            if (feed.exhausted && feed.pos >= feed.end) break;
+            continue;   // the chunk ran dry in the middle of a refill: take the next one
+        }
 
         // phase A: walk boxes until this lane stands on a passed leaf
         while (idx >= 0 && node < s.n_nodes && leaf_n == 0) {
@@ -193,7 +248,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     uint2 *my_stack = lds_stack + (threadIdx.x >> 6) * (kStackLds * 64) + lane;
     uint2 spill[kStackSpill];
     int32_t idx = -1;
-    bool exhausted = false;
+    RayFeed feed;
     Ray<float> r;
     Hit<float> h;
     uint32_t cur = 0;            // interior record when tri_n == 0
@@ -241,35 +296,29 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 
     for (;;) {
         uint64_t active = __ballot(idx >= 0);
-        if (!exhausted && (int)__popcll(active) < refill_below) {
-            const uint64_t idle = ~active;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const int leader = __ffsll((unsigned long long)idle) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(next, n_idle);
-            base = __shfl(base, leader);
-            if (idx < 0) {
-                const uint32_t mine = base + (uint32_t)__popcll(idle & lanemask_lt());
-                if (mine < n) {
-                    const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
-                    const f4 a = rp[0], b = rp[1];
-                    ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
-                    h.t = a.w;
-                    h.u = 0;
-                    h.v = 0;
-                    h.pos = -1;
-                    sp = 0;
-                    idx = (int32_t)mine;
-                    if (!enter(s.fast_root)) {   // cannot happen for a non-empty scene
-                        *reinterpret_cast<f4 *>(hits + idx) = f4{i2f(-1), h.t, 0.0f, 0.0f};
-                        idx = -1;
-                    }
+        if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
+            const int32_t mine = feed_take(feed, next, n, ~active);
+            if (mine >= 0) {
+                const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
+                const f4 a = rp[0], b = rp[1];
+                ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
+                h.t = a.w;
+                h.u = 0;
+                h.v = 0;
+                h.pos = -1;
+                sp = 0;
+                idx = mine;
+                if (!enter(s.fast_root)) {   // cannot happen for a non-empty scene
+                    *reinterpret_cast<f4 *>(hits + idx) = f4{i2f(-1), h.t, 0.0f, 0.0f};
+                    idx = -1;
                 }
             }
-            if (base + n_idle >= n || base + n_idle < base) exhausted = true;
             active = __ballot(idx >= 0);
         }
-        if (active == 0) break;
+        if (active == 0) {
+            if (feed.exhausted && feed.pos >= feed.end) break;
+            continue;   // the chunk ran dry in the middle of a refill: take the next one
+        }
 
         // phase A: lanes standing on an interior record descend until they reach a
         // leaf or run out of work
@@ -416,7 +465,7 @@ __device__ __forceinline__ void store3(float *base, size_t i, const v3 &v) {
 }
 
 // Path vertex k.  Reads queue (k & 1), writes queue ((k+1) & 1).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kShadeBlock)
 k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = id < b.P && w.state[id] == kActive;
@@ -467,7 +516,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         if (at_vertex)
             cast = shadow_candidate(s, p, point, normal, diffuse,
                                     lbase + (uint64_t)k * (uint64_t)p.L + (uint64_t)i, dn, dist, col);
-        const uint32_t q = wave_append(out_count, cast);
+        const uint32_t q = block_append(out_count, cast, i);
         if (at_vertex) {
             const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
             if (cast) {
@@ -497,7 +546,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
             bounce = true;
         }
     }
-    const uint32_t bq = wave_append(out_count, bounce);
+    const uint32_t bq = block_append(out_count, bounce, p.L);
     if (bounce) {
         f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + bq);
         rp[0] = f4{point.x, point.y, point.z, kF32Max};
@@ -1019,7 +1068,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, d, pp, b, w);
             if ((st = timed_trace(w.rays[0], b.P, w.counts + 0, w.hits[0])) != RT_OK) return st;
             for (int k = 0; k <= B; ++k) {
-                hipLaunchKernelGGL(k_shade, grid, block, 0, stream, d, pp, b, w, k);
+                hipLaunchKernelGGL(k_shade, dim3((b.P + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, d, pp, b, w, k);
                 const int o = (k + 1) & 1;
                 if ((st = timed_trace(w.rays[o], qcap, w.counts + k + 1, w.hits[o])) != RT_OK) return st;
             }
