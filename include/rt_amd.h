@@ -173,10 +173,12 @@ rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
 /* Launch parameters of the traversal kernels, for experiments: entries of the
  * per-lane stack kept in LDS (8, 12, 16 or 24; deeper entries spill), the
- * active-lane count below which a wave refills its idle lanes (1..64), and
- * persistent blocks per CU.  Results do not depend on them. */
+ * active-lane count below which a wave refills its idle lanes (1..64),
+ * persistent blocks per CU, and the number of still-descending lanes below
+ * which a wave of the ordered kernel turns to the lanes that wait on a leaf
+ * (1..64).  Results do not depend on them. */
 rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
-                              int32_t blocks_per_cu);
+                              int32_t blocks_per_cu, int32_t descend_min);
 /* When enabled, render calls that return rt_stats run the counting variant of
  * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
  * tris_tested (slower; for the roofline byte model, not for timed runs). */
@@ -217,8 +219,9 @@ rt_status rt_trace_rays(rt_scene *scene, const rt_ray *rays, size_t n, rt_hit *h
 rt_status rt_trace_rays_device(rt_scene *scene, const void *d_rays, size_t n, void *d_hits,
                                int32_t mode, void *stream);
 /* Same with per-launch traversal counters accumulated into d_counters
- * (5 x uint64 on the device: rays, nodes_visited, box_tests, tris_fetched,
- * tris_tested). */
+ * (8 x uint64 on the device: rays, nodes_visited, box_tests, tris_fetched,
+ * tris_tested, then three wave-level iteration counts of the ordered kernel:
+ * descend steps, leaf steps, lanes active in leaf steps). */
 rt_status rt_trace_rays_device_counted(rt_scene *scene, const void *d_rays, size_t n,
                                        void *d_hits, int32_t mode, void *d_counters,
                                        void *stream);

@@ -19,6 +19,8 @@
 // are 16-byte loads, compact records, full occupancy and wave-level queueing.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -240,7 +242,7 @@ template <bool COUNT, int kStackLds>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters, int refill_below) {
+             unsigned long long *counters, int refill_below, int descend_min) {
     constexpr int kStackSpill = kStackTotal - kStackLds;
     __shared__ uint2 lds_stack[4 * kStackLds * 64];
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -254,7 +256,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     uint32_t cur = 0;            // interior record when tri_n == 0
     int32_t tri_i = 0, tri_n = 0;   // next triangle and how many remain in the current leaf
     int32_t sp = 0;
-    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
+    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
 
     auto push = [&](uint32_t ref, float tn) {
         const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
@@ -322,11 +324,18 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 
         // phase A: lanes standing on an interior record descend until they reach a
         // leaf or run out of work
+        // leave the descent once fewer than descend_min lanes still descend while
+        // others already wait on a leaf: one long descent must not idle the wave
         bool alive = true;
-        while (idx >= 0 && alive && tri_n == 0) {
+        for (;;) {
+            const bool descending = idx >= 0 && alive && tri_n == 0;
+            const uint64_t m_desc = __ballot(descending);
+            if (m_desc == 0) break;
+            if ((int)__popcll(m_desc) < descend_min && __ballot(idx >= 0 && alive && tri_n > 0) != 0) break;
+            if (!descending) continue;
             const f4 *q = s.pairs + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) { c_nodes++; c_box += 2; }
+            if (COUNT) { c_nodes++; c_box += 2; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // slabs with the reference's arithmetic, (bound - origin) * invDir
             const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.w - r.ox) * r.ix;
             const float ly0 = (q0.y - r.oy) * r.iy, ly1 = (q1.x - r.oy) * r.iy;
@@ -362,7 +371,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 const f4 *qb = qa + (two ? 3 : 0);
                 const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
                 const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-                if (COUNT) c_fetch += two ? 2 : 1;
+                if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
                 bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
                 if (COUNT && tested) c_test++;
                 if (two) {
@@ -388,7 +397,13 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         c_box = wave_sum(c_box);
         c_fetch = wave_sum(c_fetch);
         c_test = wave_sum(c_test);
+        c_wa = wave_sum(c_wa);
+        c_wb = wave_sum(c_wb);
+        c_lb = wave_sum(c_lb);
         if (lane == 0) {
+            atomicAdd(counters + 5, (unsigned long long)c_wa);
+            atomicAdd(counters + 6, (unsigned long long)c_wb);
+            atomicAdd(counters + 7, (unsigned long long)c_lb);
             atomicAdd(counters + 1, (unsigned long long)c_nodes);
             atomicAdd(counters + 2, (unsigned long long)c_box);
             atomicAdd(counters + 3, (unsigned long long)c_fetch);
@@ -825,13 +840,13 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         if (sc.d_pairs) {
             const int rb = sc.tune_refill;
             if (d_counters) {
-                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb);
+                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min);
             } else {
                 switch (sc.tune_stack) {
-                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
-                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
-                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
-                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb); break;
+                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
+                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
+                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
                 }
             }
             break;
@@ -887,8 +902,8 @@ rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits,
     TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_hits), n * sizeof(rt_hit)));
     TRY_CLEAN(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     if (want_counters) {
-        TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_cnt), 5 * sizeof(unsigned long long)));
-        TRY_CLEAN(hipMemset(d_cnt, 0, 5 * sizeof(unsigned long long)));
+        TRY_CLEAN(hipMalloc(reinterpret_cast<void **>(&d_cnt), 8 * sizeof(unsigned long long)));
+        TRY_CLEAN(hipMemset(d_cnt, 0, 8 * sizeof(unsigned long long)));
     }
     TRY_CLEAN(hipEventCreate(&e0));
     TRY_CLEAN(hipEventCreate(&e1));
@@ -1029,7 +1044,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     const DevScene d = dev_view(sc);
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
     HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
-    HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 5 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 8 * sizeof(unsigned long long), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     if (stats) {
@@ -1105,8 +1120,11 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
         HIP_TRY(hipMemcpy(&total, w.ray_total, 8, hipMemcpyDeviceToHost));
         stats->rays = total;
         if (sc.count_traversal) {
-            unsigned long long c[5];
+            unsigned long long c[8];
             HIP_TRY(hipMemcpy(c, w.trav_counters, sizeof c, hipMemcpyDeviceToHost));
+            if (std::getenv("RT_DIAG"))
+                std::fprintf(stderr, "[rt diag] lane-visits A %llu wave-iters A %llu (util %.3f) lane-iters B %llu wave-iters B %llu (util %.3f)\n",
+                             c[1], c[5], c[5] ? (double)c[1] / (64.0 * c[5]) : 0.0, c[7], c[6], c[6] ? (double)c[7] / (64.0 * c[6]) : 0.0);
             stats->nodes_visited = c[1];
             stats->box_tests = c[2];
             stats->tris_fetched = c[3];
