@@ -169,16 +169,18 @@ rt_status rt_png_decode(const uint8_t *data, size_t size, uint8_t *rgba, size_t 
 rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_t *rgba,
                                int32_t width, int32_t height);
 /* Upper bound on camera samples traced together by the tile renderer (sets
- * the size of its device workspace); default 4194304. */
+ * the size of its device workspace, about 370 bytes per sample at 4 bounces
+ * and 1 light sample); default 33554432. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
 /* Launch parameters of the traversal kernels, for experiments: entries of the
  * per-lane stack kept in LDS (8, 12, 16 or 24; deeper entries spill), the
  * active-lane count below which a wave refills its idle lanes (1..64),
  * persistent blocks per CU, and the number of still-descending lanes below
- * which a wave of the ordered kernel turns to the lanes that wait on a leaf
- * (1..64).  Results do not depend on them. */
+ * which a wave of the ordered kernel turns to the lanes that wait on a leaf,
+ * and the number of lanes inside a leaf below which it turns back (both
+ * 1..64).  Results do not depend on them. */
 rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
-                              int32_t blocks_per_cu, int32_t descend_min);
+                              int32_t blocks_per_cu, int32_t descend_min, int32_t leaf_min);
 /* When enabled, render calls that return rt_stats run the counting variant of
  * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
  * tris_tested (slower; for the roofline byte model, not for timed runs). */

@@ -95,7 +95,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_int32)]),
     "rt_scene_set_texture": (C.c_int32, [vp, C.c_int32, vp, C.c_int32, C.c_int32]),
     "rt_scene_set_max_paths": (C.c_int32, [vp, C.c_uint64]),
-    "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_scene_set_counters": (C.c_int32, [vp, C.c_int32]),
     "rt_scene_destroy": (None, [vp]),
     "rt_trace_rays": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, C.c_int32, C.POINTER(Stats)]),

@@ -12,11 +12,17 @@ namespace rt {
 
 namespace {
 
-// Child-pair records for the ordered traversal.  Leaves larger than the 7-bit
-// count field are cut into a chain of synthetic interior records that reuse the
-// leaf's box; an empty leaf (the reference can create one, bvh.go:94-100 with
-// BVHMaxLeafSize 1) gets NaN bounds that no ray enters.
+// Child-pair records for the ordered traversal.  The reference's leaves hold
+// up to BVHMaxLeafSize triangles; here a leaf with more than kFastSplitLeaf is
+// cut in two by array position (the range is sorted along its parent's split
+// axis, bvh.go:73-76, so the halves are spatially separate) under synthetic
+// interior records with tight boxes, until every leaf is small: triangle tests
+// are the poorly-vectorised part of the traversal.  Array positions, and with
+// them hit ids and tie-breaking, are unchanged.  An empty leaf (the reference
+// can create one, bvh.go:94-100 with BVHMaxLeafSize 1) gets NaN bounds that no
+// ray enters.
 struct PairBuilder {
+    const rt_mesh &mesh;
     const Bvh &bvh;
     const std::vector<int32_t> &skip;
     std::vector<float> &pairs;
@@ -35,15 +41,34 @@ struct PairBuilder {
         }
         p[12 + side] = rtc::i2f((int32_t)ref);
     }
-    // reference to a triangle range with the given box
-    uint32_t leaf_ref(int32_t start, int32_t count, const float mn[3], const float mx[3]) {
-        if (count <= rtc::kFastMaxLeaf)
+    // bounds of the triangles at array positions [start, start+count)
+    void range_box(int32_t start, int32_t count, float mn[3], float mx[3]) const {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::numeric_limits<float>::max();
+            mx[k] = -std::numeric_limits<float>::max();
+        }
+        for (int32_t i = start; i < start + count; ++i) {
+            const float *v = mesh.verts + 9 * (size_t)bvh.order[(size_t)i];
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    const float c = v[3 * j + k];
+                    if (c < mn[k]) mn[k] = c;
+                    if (c > mx[k]) mx[k] = c;
+                }
+        }
+    }
+    // reference to a triangle range
+    uint32_t leaf_ref(int32_t start, int32_t count) {
+        if (count <= rtc::kFastSplitLeaf)
             return rtc::kLeafBit | ((uint32_t)count << 24) | (uint32_t)start;
         const uint32_t rec = new_record();
         const int32_t half = count / 2;
-        const uint32_t l = leaf_ref(start, half, mn, mx);
-        const uint32_t r = leaf_ref(start + half, count - half, mn, mx);
+        float mn[3], mx[3];
+        const uint32_t l = leaf_ref(start, half);
+        range_box(start, half, mn, mx);
         set_child(rec, 0, mn, mx, l);
+        const uint32_t r = leaf_ref(start + half, count - half);
+        range_box(start + half, count - half, mn, mx);
         set_child(rec, 1, mn, mx, r);
         return rec;
     }
@@ -58,7 +83,7 @@ struct PairBuilder {
             for (int k = 0; k < 3; ++k) { mn[k] = nan_; mx[k] = nan_; }
             return rtc::kLeafBit;   // count 0
         }
-        return leaf_ref(start, count, mn, mx);
+        return leaf_ref(start, count);
     }
     std::vector<uint32_t> record_of;   // interior node -> record index
 };
@@ -68,7 +93,7 @@ void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t>
     out.fast_ok = false;
     out.fast_root = 0;
     if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
-    PairBuilder b{bvh, skip, out.pairs, std::numeric_limits<float>::quiet_NaN(), {}};
+    PairBuilder b{mesh, bvh, skip, out.pairs, std::numeric_limits<float>::quiet_NaN(), {}};
     const int32_t nn = bvh.n_nodes;
     b.record_of.assign((size_t)nn, 0);
     for (int32_t i = 0; i < nn; ++i)
@@ -84,6 +109,11 @@ void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t>
         b.set_child(rec, 1, mn, mx, rref);
     }
     out.fast_root = b.child_ref(0, mn, mx);   // the root is entered without a box test
+    if (out.fast_root == rtc::kLeafBit) {     // a tree whose root is an empty leaf has nothing to traverse in order
+        out.pairs.clear();
+        out.fast_root = 0;
+        return;
+    }
     if (out.pairs.empty()) out.pairs.resize(16, 0.0f);
     out.fast_ok = true;
 }

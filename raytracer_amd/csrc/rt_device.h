@@ -62,11 +62,12 @@ struct Scene {
     std::vector<uint8_t *> tex_ptrs;
     std::vector<int32_t> tex_dims;
     // path-tracing workspace (grow-only)
-    size_t max_paths_in_flight = (size_t)1 << 22;
+    size_t max_paths_in_flight = (size_t)1 << 25;
     // launch tuning (defaults chosen by measurement; overridable for experiments)
     int tune_stack = 8;           // LDS stack entries per lane of the fast kernel
     int tune_refill = 60;         // refill idle lanes once fewer than this many are active
     int tune_blocks_per_cu = 8;   // persistent grid size
+    int tune_leaf_min = 8;        // fast kernel: leave the leaf phase below this many lanes in a leaf
     int tune_descend_min = 24;    // fast kernel: leave the descent phase below this many descending lanes
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;

@@ -242,7 +242,7 @@ template <bool COUNT, int kStackLds>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters, int refill_below, int descend_min) {
+             unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
     constexpr int kStackSpill = kStackTotal - kStackLds;
     __shared__ uint2 lds_stack[4 * kStackLds * 64];
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -256,6 +256,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     uint32_t cur = 0;            // interior record when tri_n == 0
     int32_t tri_i = 0, tri_n = 0;   // next triangle and how many remain in the current leaf
     int32_t sp = 0;
+    bool alive = false;          // this lane's ray still has work
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
 
     auto push = [&](uint32_t ref, float tn) {
@@ -264,39 +265,46 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         else if (sp < kStackTotal) spill[sp - kStackLds] = e;
         sp++;   // deeper than both levels cannot happen: trees deeper than 60 use the other kernel
     };
-    // Moves the lane to `ref`, or to the next stacked entry that can still hold
-    // a closer hit; returns false when the ray is finished.
-    auto enter = [&](uint32_t ref) -> bool {
-        for (;;) {
-            if (ref != kRefDone) {
-                if ((ref & kLeafBit) == 0) {
-                    cur = ref;
-                    tri_n = 0;
-                    return true;
-                }
-                const int32_t count = (int32_t)((ref >> 24) & 0x7Fu);
-                if (count > 0) {
-                    tri_i = (int32_t)(ref & 0xFFFFFFu);
-                    tri_n = count;
-                    return true;
-                }
-            }
-            ref = kRefDone;
-            while (sp > 0) {
-                sp--;
-                uint2 e;
-                if (sp < kStackLds) e = my_stack[sp * 64];
-                else e = spill[sp - kStackLds];
-                if (i2f((int32_t)e.y) < h.t) {
-                    ref = e.x;
-                    break;
-                }
-            }
-            if (ref == kRefDone) return false;
+    // Stands the lane on `ref`: an interior record, or a leaf (never empty: empty
+    // leaves carry NaN boxes that no ray enters).
+    auto stand_on = [&](uint32_t ref) {
+        if ((ref & kLeafBit) == 0) {
+            cur = ref;
+            tri_n = 0;
+        } else {
+            tri_i = (int32_t)(ref & 0xFFFFFFu);
+            tri_n = (int32_t)((ref >> 24) & 0x7Fu);
         }
+    };
+    // Next stacked entry that can still hold a closer hit; false when the ray is
+    // finished.  The LDS slot is read unconditionally (index clamped) and replaced
+    // from the spill array only when the entry lives there, so that both accesses
+    // keep their own address space.
+    auto pop_next = [&]() -> bool {
+        while (sp > 0) {
+            sp--;
+            uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
+            asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
+            if (sp >= kStackLds) e = spill[sp - kStackLds];
+            if (i2f((int32_t)e.y) < h.t) {
+                stand_on(e.x);
+                return true;
+            }
+        }
+        return false;
     };
 
     for (;;) {
+        // retire finished rays, refill idle lanes
+        if (idx >= 0 && !alive) {
+            f4 out;
+            out.x = i2f(h.pos);
+            out.y = h.t;
+            out.z = h.u;
+            out.w = h.v;
+            *reinterpret_cast<f4 *>(hits + idx) = out;
+            idx = -1;
+        }
         uint64_t active = __ballot(idx >= 0);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
             const int32_t mine = feed_take(feed, next, n, ~active);
@@ -310,10 +318,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 h.pos = -1;
                 sp = 0;
                 idx = mine;
-                if (!enter(s.fast_root)) {   // cannot happen for a non-empty scene
-                    *reinterpret_cast<f4 *>(hits + idx) = f4{i2f(-1), h.t, 0.0f, 0.0f};
-                    idx = -1;
-                }
+                alive = true;
+                stand_on(s.fast_root);
             }
             active = __ballot(idx >= 0);
         }
@@ -322,11 +328,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             continue;   // the chunk ran dry in the middle of a refill: take the next one
         }
 
-        // phase A: lanes standing on an interior record descend until they reach a
-        // leaf or run out of work
-        // leave the descent once fewer than descend_min lanes still descend while
-        // others already wait on a leaf: one long descent must not idle the wave
-        bool alive = true;
+        // phase A: lanes standing on an interior record descend.  The phase ends
+        // once fewer than descend_min lanes still descend while others wait on a
+        // leaf: one long descent must not idle the wave.
         for (;;) {
             const bool descending = idx >= 0 && alive && tri_n == 0;
             const uint64_t m_desc = __ballot(descending);
@@ -350,46 +354,46 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool hl = ln <= lf && ln < h.t && lf > 0;
             const bool hr = rn <= rf && rn < h.t && rf > 0;
             const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
-            uint32_t nxt = kRefDone;
             if (hl && hr) {
                 const bool left_first = ln <= rn;
                 push(left_first ? rref : lref, left_first ? rn : ln);
-                nxt = left_first ? lref : rref;
-            } else if (hl) {
-                nxt = lref;
-            } else if (hr) {
-                nxt = rref;
+                stand_on(left_first ? lref : rref);
+            } else if (hl || hr) {
+                stand_on(hl ? lref : rref);
+            } else {
+                alive = pop_next();
             }
-            alive = enter(nxt);
         }
-        // phase B: the leaf's triangles in array order, two fetched at a time so
-        // that their loads overlap
-        if (idx >= 0 && alive && tri_n > 0) {
-            for (; tri_n > 0; tri_i += 2, tri_n -= 2) {
-                const bool two = tri_n > 1;
-                const f4 *qa = s.tris + 3 * (size_t)tri_i;
-                const f4 *qb = qa + (two ? 3 : 0);
-                const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
-                const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-                if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
-                bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
+        // phase B: lanes holding a leaf test its triangles in array order, two
+        // fetched at a time so that their loads overlap; a lane that finishes its
+        // leaf takes its next stack entry at once.  The phase ends when no lane
+        // holds a leaf, or when fewer than leaf_min do while enough lanes wait to
+        // descend (the few keep their place in the leaf for the next round).
+        for (;;) {
+            const bool in_leaf = idx >= 0 && alive && tri_n > 0;
+            const uint64_t m_leaf = __ballot(in_leaf);
+            if (m_leaf == 0) break;
+            if ((int)__popcll(m_leaf) < leaf_min &&
+                (int)__popcll(__ballot(idx >= 0 && alive && tri_n == 0)) >= descend_min) break;
+            if (!in_leaf) continue;
+            const bool two = tri_n > 1;
+            const f4 *qa = s.tris + 3 * (size_t)tri_i;
+            const f4 *qb = qa + (two ? 3 : 0);
+            const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
+            const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
+            if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
+            bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
+            if (COUNT && tested) c_test++;
+            if (two) {
+                tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
                 if (COUNT && tested) c_test++;
-                if (two) {
-                    tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
-                    if (COUNT && tested) c_test++;
-                }
             }
-            tri_n = 0;
-            alive = enter(kRefDone);
-        }
-        if (idx >= 0 && !alive) {
-            f4 out;
-            out.x = i2f(h.pos);
-            out.y = h.t;
-            out.z = h.u;
-            out.w = h.v;
-            *reinterpret_cast<f4 *>(hits + idx) = out;
-            idx = -1;
+            tri_i += 2;
+            tri_n -= 2;
+            if (tri_n <= 0) {
+                tri_n = 0;
+                alive = pop_next();
+            }
         }
     }
     if (COUNT) {
@@ -840,13 +844,13 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         if (sc.d_pairs) {
             const int rb = sc.tune_refill;
             if (d_counters) {
-                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min);
+                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min);
             } else {
                 switch (sc.tune_stack) {
-                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
-                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
-                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
-                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min); break;
+                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
+                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
+                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
                 }
             }
             break;

@@ -195,7 +195,8 @@ def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul):
     assert mismatch <= 3, mismatch
     same = hits["tri_pos"] == ref["tri"]
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
-    assert st["nodes_visited"] < ref["counters"]["nodes_visited"]
+    c = ref["counters"]
+    assert 56 * st["nodes_visited"] + 48 * st["tris_fetched"] < 56 * c["nodes_visited"] + 48 * c["tris_fetched"]
 
 
 def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
