@@ -127,24 +127,33 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 // ---------------------------------------------------------------------------
 // Traversal, reference order.  One lane = one ray; the wave is persistent.
 // ---------------------------------------------------------------------------
-constexpr int kRefillBelow = 40;   // refill idle lanes once fewer are active
 
 template <typename Real, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-            unsigned long long *counters) {
+            unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
     const uint32_t n = n_dev ? *n_dev : n_host;
     int32_t idx = -1;            // ray owned by this lane, -1 = idle
     RayFeed feed;
     Ray<Real> r;
     Hit<Real> h;
-    int32_t node = 0, leaf_a = 0, leaf_n = 0;
+    int32_t node = 0, leaf_a = 0, leaf_n = 0;   // next node in preorder; triangles left in the passed leaf
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
 
     for (;;) {
+        // retire rays that walked past the last node, refill idle lanes
+        if (idx >= 0 && node >= s.n_nodes && leaf_n == 0) {
+            f4 out;
+            out.x = i2f(h.pos);
+            out.y = (float)h.t;
+            out.z = (float)h.u;
+            out.w = (float)h.v;
+            *reinterpret_cast<f4 *>(hits + idx) = out;
+            idx = -1;
+        }
         uint64_t active = __ballot(idx >= 0);
-        if (!(feed.exhausted && feed.pos >= feed.end) && __popcll(active) < kRefillBelow) {
+        if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
             const int32_t mine = feed_take(feed, next, n, ~active);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
@@ -165,8 +174,15 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             continue;   // the chunk ran dry in the middle of a refill: take the next one
         }
 
-        // phase A: walk boxes until this lane stands on a passed leaf
-        while (idx >= 0 && node < s.n_nodes && leaf_n == 0) {
+        // phase A: walk boxes in the reference's order until this lane stands on a
+        // passed leaf; the phase ends once fewer than descend_min lanes still walk
+        // while others wait on a leaf
+        for (;;) {
+            const bool walking = idx >= 0 && node < s.n_nodes && leaf_n == 0;
+            const uint64_t m_walk = __ballot(walking);
+            if (m_walk == 0) break;
+            if ((int)__popcll(m_walk) < descend_min && __ballot(idx >= 0 && leaf_n > 0) != 0) break;
+            if (!walking) continue;
             const f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
             const int32_t a = f2i(lo.w), b = f2i(hi.w);
             bool pass = true;
@@ -186,25 +202,22 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
                 node = pass ? node + 1 : a;
             }
         }
-        // phase B: the leaf's triangles, in array order
-        if (idx >= 0 && leaf_n > 0) {
-            for (int32_t k = 0; k < leaf_n; ++k) {
-                const f4 *q = s.tris + 3 * (size_t)(leaf_a + k);
-                const f4 q0 = q[0], q1 = q[1], q2 = q[2];
-                if (COUNT) c_fetch++;
-                const bool tested = tri_test(r, q0, q1, q2, leaf_a + k, h);
-                if (COUNT && tested) c_test++;
-            }
-            leaf_n = 0;
-        }
-        if (idx >= 0 && node >= s.n_nodes) {
-            f4 out;
-            out.x = i2f(h.pos);
-            out.y = (float)h.t;
-            out.z = (float)h.u;
-            out.w = (float)h.v;
-            *reinterpret_cast<f4 *>(hits + idx) = out;
-            idx = -1;
+        // phase B: the leaf's triangles, in array order; ends when no lane holds a
+        // leaf, or when fewer than leaf_min do while enough lanes wait to walk
+        for (;;) {
+            const bool in_leaf = idx >= 0 && leaf_n > 0;
+            const uint64_t m_leaf = __ballot(in_leaf);
+            if (m_leaf == 0) break;
+            if ((int)__popcll(m_leaf) < leaf_min &&
+                (int)__popcll(__ballot(idx >= 0 && node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
+            if (!in_leaf) continue;
+            const f4 *q = s.tris + 3 * (size_t)leaf_a;
+            const f4 q0 = q[0], q1 = q[1], q2 = q[2];
+            if (COUNT) c_fetch++;
+            const bool tested = tri_test(r, q0, q1, q2, leaf_a, h);
+            if (COUNT && tested) c_test++;
+            leaf_a++;
+            leaf_n--;
         }
     }
     if (COUNT) {
@@ -859,15 +872,15 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         [[fallthrough]];
     case RT_MODE_STRICT_F32:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
         else
-            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
         break;
     case RT_MODE_FP64:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
         else
-            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters);
+            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
         break;
     default:
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
