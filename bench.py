@@ -188,11 +188,20 @@ def main():
             light_samples=wl["light_samples"], intensity=wl["intensity"], seed=seed,
             x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid))
 
+    pass_cache = {}
+
     def render_tiles(group, step):
         """One call for a whole group of tiles: one ray queue per path depth for
-        the group, so small tiles still fill the GPU."""
-        passes = [make_pass(t, args.spp, 1 + 1000 * step) for t in group]
-        return scene.render_tiles_device(passes, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
+        the group, so small tiles still fill the GPU.  The pass records of a group
+        are built once; a new frame only changes the per-tile seeds (the frontend
+        sends base seed + task id, Renderer.js:423)."""
+        key = group[0][0], len(group)
+        arr = pass_cache.get(key)
+        if arr is None:
+            arr = pass_cache[key] = api.pass_array([make_pass(t, args.spp, 0) for t in group])
+        for i, t in enumerate(group):
+            arr[i].rng_seed = 1 + 1000 * step + t[0]
+        return scene.render_tiles_device(arr, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
                                          stream=stream, want_stats=True)
 
     def run_step(step, collect):

@@ -109,7 +109,8 @@ rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float
 
 /* The second flat view used by RT_MODE_FAST_F32: one 64-byte record per
  * interior node holding both children's boxes and references, 16 floats each:
- * (L.min.xyz, L.max.xyz, R.min.xyz, R.max.xyz, bits L.ref, bits R.ref, 0, 0);
+ * (L.min.x, L.max.x, L.min.y, L.max.y, L.min.z, L.max.z, then the same six
+ * for R, bits L.ref, bits R.ref, 0, 0);
  * ref = record index, or for a leaf 0x80000000 | count << 24 | first triangle.
  * Call with records == NULL to get the count.  *root_ref is the ref traversal
  * starts from. */

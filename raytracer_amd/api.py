@@ -272,8 +272,9 @@ class Scene:
     def render_tiles_device(self, passes, d_accum_ptr, d_rgba_ptr, mode=MODE_STRICT_F32,
                             stream=None, want_stats=False):
         """Several tiles of one frame in one call; pixels of tile i follow those of
-        tile i-1 in both device buffers."""
-        arr = (Pass * len(passes))(*passes)
+        tile i-1 in both device buffers.  `passes` is a list of Pass or a ready
+        ctypes array of them (see pass_array)."""
+        arr = passes if isinstance(passes, C.Array) else (Pass * len(passes))(*passes)
         st = Stats() if want_stats else None
         check(lib().rt_render_tiles_device(self._h, arr, len(passes), mode, d_accum_ptr,
                                            d_rgba_ptr, C.byref(st) if st is not None else None,
@@ -287,6 +288,12 @@ class Scene:
                                          d_accum_ptr, d_rgba_ptr,
                                          C.byref(st) if st is not None else None, stream))
         return st.as_dict() if st is not None else None
+
+
+def pass_array(passes):
+    """ctypes array of Pass for render_tiles_device, reusable across calls (the
+    caller may update fields such as rng_seed in place between frames)."""
+    return (Pass * len(passes))(*passes)
 
 
 def pass_from_dict(d):

@@ -33,12 +33,12 @@ struct PairBuilder {
         return (uint32_t)(pairs.size() / 16 - 1);
     }
     void set_child(uint32_t rec, int side, const float mn[3], const float mx[3], uint32_t ref) {
-        float *p = &pairs[(size_t)rec * 16];
-        if (side == 0) {
-            p[0] = mn[0]; p[1] = mn[1]; p[2] = mn[2]; p[3] = mx[0]; p[4] = mx[1]; p[5] = mx[2];
-        } else {
-            p[6] = mn[0]; p[7] = mn[1]; p[8] = mn[2]; p[9] = mx[0]; p[10] = mx[1]; p[11] = mx[2];
+        float *p = &pairs[(size_t)rec * 16 + (size_t)side * 6];
+        for (int k = 0; k < 3; ++k) {
+            p[2 * k] = mn[k];
+            p[2 * k + 1] = mx[k];
         }
+        p = &pairs[(size_t)rec * 16];
         p[12 + side] = rtc::i2f((int32_t)ref);
     }
     // bounds of the triangles at array positions [start, start+count)

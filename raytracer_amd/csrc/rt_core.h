@@ -65,8 +65,10 @@ struct DevScene {
     const int32_t *tex_dim;     // per slot (w, h)
     // Ordered-traversal view of the same tree (fast mode): one 64-byte record
     // per interior node holding BOTH children's boxes and references,
-    //   [0] = (L.min.xyz, L.max.x) [1] = (L.max.yz, R.min.xy) [2] = (R.min.z, R.max.xyz)
-    //   [3] = (bits L.ref, bits R.ref, 0, 0)
+    //   [0] = (L.min.x, L.max.x, L.min.y, L.max.y) [1] = (L.min.z, L.max.z, R.min.x, R.max.x)
+    //   [2] = (R.min.y, R.max.y, R.min.z, R.max.z)   [3] = (bits L.ref, bits R.ref, 0, 0)
+    // (min and max of one axis side by side: the two slab distances of an axis
+    // come out of one packed subtract and one packed multiply)
     // ref: interior -> record index; leaf -> kLeafBit | count << 24 | first triangle.
     const f4 *pairs;
     uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
@@ -216,12 +218,12 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
             const f4 *q = s.pairs + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c->nodes_visited++; c->box_tests += 2; }
-            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.w - r.ox) * r.ix;
-            const float ly0 = (q0.y - r.oy) * r.iy, ly1 = (q1.x - r.oy) * r.iy;
-            const float lz0 = (q0.z - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
-            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q2.y - r.ox) * r.ix;
-            const float ry0 = (q1.w - r.oy) * r.iy, ry1 = (q2.z - r.oy) * r.iy;
-            const float rz0 = (q2.x - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
+            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.y - r.ox) * r.ix;
+            const float ly0 = (q0.z - r.oy) * r.iy, ly1 = (q0.w - r.oy) * r.iy;
+            const float lz0 = (q1.x - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
+            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q1.w - r.ox) * r.ix;
+            const float ry0 = (q2.x - r.oy) * r.iy, ry1 = (q2.y - r.oy) * r.iy;
+            const float rz0 = (q2.z - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
             const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
             const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
             const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));

@@ -250,6 +250,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // would accept.
 // ---------------------------------------------------------------------------
 constexpr int kStackTotal = 64;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <bool COUNT, int kStackLds>
 __global__ void __launch_bounds__(256)
@@ -353,17 +354,19 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const f4 *q = s.pairs + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c_nodes++; c_box += 2; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
-            // slabs with the reference's arithmetic, (bound - origin) * invDir
-            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.w - r.ox) * r.ix;
-            const float ly0 = (q0.y - r.oy) * r.iy, ly1 = (q1.x - r.oy) * r.iy;
-            const float lz0 = (q0.z - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
-            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q2.y - r.ox) * r.ix;
-            const float ry0 = (q1.w - r.oy) * r.iy, ry1 = (q2.z - r.oy) * r.iy;
-            const float rz0 = (q2.x - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
-            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
-            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+            // slabs with the reference's arithmetic, (bound - origin) * invDir; the
+            // record keeps an axis' two bounds side by side so that each pair is
+            // one packed subtract and one packed multiply
+            const f2 lx = (f2{q0.x, q0.y} - f2{r.ox, r.ox}) * f2{r.ix, r.ix};
+            const f2 ly = (f2{q0.z, q0.w} - f2{r.oy, r.oy}) * f2{r.iy, r.iy};
+            const f2 lz = (f2{q1.x, q1.y} - f2{r.oz, r.oz}) * f2{r.iz, r.iz};
+            const f2 rx = (f2{q1.z, q1.w} - f2{r.ox, r.ox}) * f2{r.ix, r.ix};
+            const f2 ry = (f2{q2.x, q2.y} - f2{r.oy, r.oy}) * f2{r.iy, r.iy};
+            const f2 rz = (f2{q2.z, q2.w} - f2{r.oz, r.oz}) * f2{r.iz, r.iz};
+            const float ln = fmaxf(fmaxf(fminf(lx.x, lx.y), fminf(ly.x, ly.y)), fminf(lz.x, lz.y));
+            const float lf = fminf(fminf(fmaxf(lx.x, lx.y), fmaxf(ly.x, ly.y)), fmaxf(lz.x, lz.y));
+            const float rn = fmaxf(fmaxf(fminf(rx.x, rx.y), fminf(ry.x, ry.y)), fminf(rz.x, rz.y));
+            const float rf = fminf(fminf(fmaxf(rx.x, rx.y), fmaxf(ry.x, ry.y)), fmaxf(rz.x, rz.y));
             const bool hl = ln <= lf && ln < h.t && lf > 0;
             const bool hr = rn <= rf && rn < h.t && rf > 0;
             const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);

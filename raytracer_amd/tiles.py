@@ -48,6 +48,26 @@ def tile_pixel_offsets(tiles):
     return offs, total
 
 
+def _paste_uniform(frame, buf, mine):
+    """All of a rank's tiles in ONE strided copy when they share one size and sit
+    on a regular lattice of the frame (the common case: the frame divides evenly
+    into the tile grid and ranks take every world-th tile).  Returns False when
+    the tiles do not fit that pattern."""
+    if not mine:
+        return True
+    _t, x0, y0, w, h = mine[0]
+    if any(t[3] != w or t[4] != h for t in mine) or frame.shape[1] % w or frame.shape[0] % h:
+        return False
+    if any(t[1] % w or t[2] % h for t in mine):
+        return False
+    cols, rows = frame.shape[1] // w, frame.shape[0] // h
+    grid = frame.view(rows, h, cols, w, 4).permute(0, 2, 1, 3, 4)      # (row, col, h, w, 4) view
+    row = torch.tensor([t[2] // h for t in mine], device=frame.device)
+    col = torch.tensor([t[1] // w for t in mine], device=frame.device)
+    grid[row, col] = buf[:len(mine) * w * h * 4].view(len(mine), h, w, 4)
+    return True
+
+
 def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None):
     """Static assignment: every rank holds the RGBA8 images of its block-cyclic
     tiles back to back in `local_rgba` (uint8, padded to the largest per-rank
@@ -61,8 +81,11 @@ def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None):
     if rank != 0:
         return None
     for r, buf in enumerate(bufs):
+        mine = tile_list[r::world]
+        if _paste_uniform(frame, buf, mine):
+            continue
         off = 0
-        for (_tid, x, y, w, h) in tile_list[r::world]:
+        for (_tid, x, y, w, h) in mine:
             frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
             off += w * h * 4
     return frame

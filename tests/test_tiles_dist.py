@@ -116,3 +116,27 @@ def test_single_rank_paths():
     frame = tiles.gather_static(buf, tile_list, 1, 0, torch.zeros((H, W, 4), dtype=torch.uint8))
     assert np.array_equal(frame.numpy(), _expected_frame())
     assert tiles.sum_counters([5, 7], "cpu", 1) == [5, 7]
+
+
+def test_uniform_paste_equals_tile_loop():
+    """The one-copy paste of a rank's tiles equals pasting them one by one, and
+    declines tilings it does not cover (remainder tiles)."""
+    import torch
+    from raytracer_amd import scenes, tiles
+    for (W, H, n, world) in [(64, 48, 4, 1), (64, 48, 4, 3), (60, 40, 4, 2), (50, 30, 4, 2)]:
+        tl = scenes.tiles(W, H, n)
+        for rank in range(world):
+            mine = tl[rank::world]
+            total = sum(t[3] * t[4] * 4 for t in mine)
+            buf = torch.randint(0, 255, (total,), dtype=torch.uint8)
+            want = torch.zeros((H, W, 4), dtype=torch.uint8)
+            off = 0
+            for (_t, x, y, w, h) in mine:
+                want[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
+                off += w * h * 4
+            got = torch.zeros((H, W, 4), dtype=torch.uint8)
+            ok = tiles._paste_uniform(got, buf, mine)
+            uniform = W % n == 0 and H % n == 0
+            assert ok == uniform or (ok and all(t[3] == mine[0][3] and t[4] == mine[0][4] for t in mine))
+            if ok:
+                assert torch.equal(got, want)
