@@ -242,8 +242,14 @@ def main():
     sample_tile = tile_list[(len(tile_list) // 2) + wl["tiles"] // 2]
     st = scene.render_tile_device(make_pass(sample_tile, 1, 1), d_accum.data_ptr(),
                                   d_tiles.data_ptr(), mode=mode, stream=stream, want_stats=True)
+    # the same sample tile in the reference's visit order: the byte count a literal
+    # left-first WalkNode (models/bvh.go:117-144) needs for these rays
+    st_ref = st if mode == api.MODE_STRICT_F32 else scene.render_tile_device(
+        make_pass(sample_tile, 1, 1), d_accum.data_ptr(), d_tiles.data_ptr(),
+        mode=api.MODE_STRICT_F32, stream=stream, want_stats=True)
     scene.set_counters(False)
     bpr = bytes_per_ray(st["nodes_visited"], st["tris_fetched"], max(st["rays"], 1))
+    bpr_ref = bytes_per_ray(st_ref["nodes_visited"], st_ref["tris_fetched"], max(st_ref["rays"], 1))
     nodes_per_ray = st["nodes_visited"] / max(st["rays"], 1)
     tris_per_ray = st["tris_fetched"] / max(st["rays"], 1)
 
@@ -302,11 +308,17 @@ def main():
                                                    "fp64": "k_trace_ref<double>"}[args.mode],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nodes_per_ray, 2),
+                         "bytes_per_ray": round(bpr, 1),
+                         "bytes_per_ray_reference_order": round(bpr_ref, 1),
+                         "nodes_per_ray": round(nodes_per_ray, 2),
                          "tris_per_ray": round(tris_per_ray, 2),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
-                         "note": "scene (64 MB) is served from L2/Infinity Cache, so algorithmic "
-                                 "bytes/s may exceed what HBM itself moves"},
+                         "note": "achieved = rays x bytes_per_ray (this kernel's own counted node and "
+                                 "triangle fetches) / traversal-launch time. The 64 MB scene is served "
+                                 "from L2 / Infinity Cache, so the algorithmic rate can exceed the HBM "
+                                 "peak; traffic = measured fabric bytes per launch (profiles/traffic.json). "
+                                 "Random 64-byte record gathers top out at 6.5 TB/s on a 10 MB table and "
+                                 "3.8 TB/s on a 64 MB table on this GPU (tools/ubench/gather.hip)"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(sc, bvh.export(), tables, wl, args, tile_list)

@@ -4,12 +4,17 @@
 //              16-byte piece each (coalesced within the quad), four turns
 //   variant 2: variant 1 + exchange through LDS so that each lane ends up with
 //              its own 64 bytes
+//   variants 3, 4, 5: 32 bytes (two loads), 16 bytes (one load), four 8-byte
+//              loads per record -- is the cost per load instruction or per byte?
+//   variant 6: 128-byte records (eight loads) out of the same table
 // The next record index depends on the data just read (pointer chasing), as in
 // tree traversal.  Build: hipcc --offload-arch=gfx950 -O3 gather.hip -o gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 struct f4 { float x, y, z, w; };
 typedef unsigned int u32;
@@ -18,11 +23,27 @@ template <int VARIANT>
 __global__ void __launch_bounds__(256) k(const uint4 *__restrict__ rec, u32 n_rec, int steps, u32 *out) {
     __shared__ uint4 xch[4 * 4 * 64];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 idx = (blockIdx.x * 256 + threadIdx.x) * 2654435761u % n_rec;
+    u32 state = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    u32 idx = (u32)(((unsigned long long)state * n_rec) >> 32);
     u32 acc = 0;
     for (int s = 0; s < steps; ++s) {
         uint4 a, b, c, d;
-        if (VARIANT == 0) {
+        if (VARIANT == 6) {          // 128-byte records: eight 16-byte loads
+            const uint4 *p = rec + 8 * (size_t)(idx >> 1);
+            const uint4 e = p[0], f = p[1], g = p[2], hh = p[3], e2 = p[4], f2 = p[5], g2 = p[6], h2 = p[7];
+            a = make_uint4(e.x ^ e2.x, e.y, e.z, e.w); b = make_uint4(f.x, f.y ^ f2.y, f.z, f.w);
+            c = make_uint4(g.x, g.y, g.z ^ g2.z, g.w); d = make_uint4(hh.x, hh.y, hh.z, hh.w ^ h2.w);
+        } else if (VARIANT == 3) {          // half of the record: two 16-byte loads
+            const uint4 *p = rec + 4 * (size_t)idx;
+            a = p[0]; b = p[1]; c = a; d = b;
+        } else if (VARIANT == 4) {   // a quarter: one 16-byte load
+            const uint4 *p = rec + 4 * (size_t)idx;
+            a = p[0]; b = a; c = a; d = a;
+        } else if (VARIANT == 5) {   // four 8-byte loads spread over the record
+            const uint2 *p = reinterpret_cast<const uint2 *>(rec + 4 * (size_t)idx);
+            const uint2 e = p[0], f = p[2], g = p[4], hh = p[6];
+            a = make_uint4(e.x, e.y, 0, 0); b = make_uint4(0, f.x, f.y, 0); c = make_uint4(0, 0, g.x, g.y); d = make_uint4(hh.x, 0, 0, hh.y);
+        } else if (VARIANT == 0) {
             const uint4 *p = rec + 4 * (size_t)idx;
             a = p[0]; b = p[1]; c = p[2]; d = p[3];
         } else {
@@ -46,12 +67,10 @@ __global__ void __launch_bounds__(256) k(const uint4 *__restrict__ rec, u32 n_re
         }
         const u32 v = a.x ^ b.y ^ c.z ^ d.w;
         acc += v;
-        if (VARIANT == 1) {
-            // every lane saw a different mix; the own record's words are spread over the quad
-            idx = (idx * 1664525u + 1013904223u + (v & 1u)) % n_rec;
-        } else {
-            idx = (idx * 1664525u + 1013904223u + (v & 1u)) % n_rec;
-        }
+        // full 32-bit generator state per lane (a walk on the indices themselves
+        // would fall into short cycles shared by all lanes and hit in cache)
+        state = state * 1664525u + 1013904223u + (v & 1u);
+        idx = (u32)(((unsigned long long)state * n_rec) >> 32);
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -63,18 +82,28 @@ int main(int argc, char **argv) {
     std::vector<u32> h((size_t)n_rec * 16);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (u32)(i * 2654435761u) >> 7;
     uint4 *d_rec; u32 *d_out;
-    hipMalloc(&d_rec, h.size() * 4);
-    hipMalloc(&d_out, (size_t)blocks * 256 * 4);
-    hipMemcpy(d_rec, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int v = 0; v < 3; ++v) {
+    CHECK(hipMalloc(&d_rec, h.size() * 4));
+    CHECK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+    CHECK(hipMemcpy(d_rec, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int only = argc > 4 ? atoi(argv[4]) : -1;   // run one variant only (for counter passes)
+    for (int v = 0; v < 7; ++v) {
+        if (only >= 0 && v != only) continue;
         for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0);
+            CHECK(hipEventRecord(e0));
             if (v == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
             if (v == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
             if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (v == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
+            if (v == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
+            if (v == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
+            if (v == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, d_rec, n_rec, steps, d_out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double recs = (double)blocks * 256 * steps;
             if (rep) printf("variant %d: %.2f ms, %.1f G records/s, %.0f GB/s\n", v, ms, recs / ms / 1e6, recs * 64 / ms / 1e6);
         }
