@@ -74,6 +74,9 @@ def lib():
         L.orc_scene_create.restype = vp
         L.orc_scene_create.argtypes = [vp, vp, vp, C.c_int32, vp, vp, C.c_int32]
         L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_set_texcoords.argtypes = [vp, vp]
+        L.orc_scene_set_texture.restype = C.c_int32
+        L.orc_scene_set_texture.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_int32]
         L.orc_build_bvh.restype = C.c_int32
         L.orc_build_bvh.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.orc_set_bvh.restype = C.c_int32
@@ -192,6 +195,19 @@ class Scene:
         if getattr(self, "_h", None):
             lib().orc_scene_destroy(self._h)
             self._h = None
+
+    def set_texcoords(self, uv):
+        """Per-vertex texture coordinates, (n, 6) in input order (context.go:138-156)."""
+        uv = _f32(uv).reshape(-1, 6)
+        assert uv.shape[0] == self.n
+        lib().orc_scene_set_texcoords(self._h, _ptr(uv))
+
+    def set_texture(self, material, rgba):
+        """The image behind one material's map_Kd: (h, w, 4) uint8."""
+        img = np.ascontiguousarray(rgba, np.uint8)
+        h, w = img.shape[:2]
+        if lib().orc_scene_set_texture(self._h, int(material), _ptr(img), w, h) != 0:
+            raise ValueError("bad texture arguments")
 
     def build_bvh(self, use_bvh=True, max_leaf=6, max_depth=16):
         return lib().orc_build_bvh(self._h, int(use_bvh), max_leaf, max_depth)

@@ -26,7 +26,14 @@ typedef struct OTriangle {
     float e0[3], e1[3], e2[3];
     int32_t material;
     int32_t is_light;
+    float tc[3][2];       /* TextureCoords (context.go:138-156), zero when the mesh has none */
 } OTriangle;
+
+/* models/texture.go:13-19: an image.RGBA behind a material's map_Kd */
+typedef struct OTexture {
+    uint8_t *pix;         /* RGBA8 rows, as image.RGBA.Pix */
+    int32_t w, h;
+} OTexture;
 
 /* models/bvh.go:17-29 + models/aabb.go:11-22 (only Bounds is used) */
 typedef struct ONode {
@@ -44,6 +51,7 @@ struct orc_scene {
     int32_t n_mat;
     float *kd;
     uint8_t *mat_light;
+    OTexture *tex;        /* per material; pix == NULL: no map_Kd / not found */
     ONode *root;
     int32_t n_nodes;
     /* build parameters */
@@ -441,6 +449,7 @@ orc_scene *orc_scene_create(const float *verts, const int32_t *material,
     s->mat_light = (uint8_t *)malloc((size_t)(m > 0 ? m : 1));
     memcpy(s->kd, kd, sizeof(float) * 3 * (size_t)m);
     memcpy(s->mat_light, is_light, (size_t)m);
+    s->tex = (OTexture *)calloc((size_t)(m > 0 ? m : 1), sizeof(OTexture));
     for (int32_t i = 0; i < n; ++i) {
         int32_t mat = material ? material[i] : 0;
         make_triangle(&s->store[i], verts + 9 * (size_t)i, mat, is_light[mat],
@@ -454,9 +463,35 @@ void orc_scene_destroy(orc_scene *s)
 {
     if (!s) return;
     free_tree(s->root);
+    if (s->tex)
+        for (int32_t i = 0; i < s->n_mat; ++i) free(s->tex[i].pix);
+    free(s->tex);
     free(s->store); free(s->tris); free(s->kd); free(s->mat_light);
     free(s->cam_tab); free(s->light_tab);
     free(s);
+}
+
+/* context.go:138-156: per-vertex texture coordinates of every triangle, in
+ * input order (n*6 floats: uv0, uv1, uv2). */
+void orc_scene_set_texcoords(orc_scene *s, const float *uv)
+{
+    for (int32_t i = 0; i < s->n; ++i)
+        memcpy(s->store[i].tc, uv + 6 * (size_t)i, sizeof(float) * 6);
+}
+
+/* context.go:85-103 TextureLookup[MapKd] for one material: RGBA8 pixels as
+ * image.RGBA holds them (texture.go:24-46). */
+int32_t orc_scene_set_texture(orc_scene *s, int32_t material, const uint8_t *rgba,
+                              int32_t w, int32_t h)
+{
+    if (material < 0 || material >= s->n_mat || w <= 0 || h <= 0 || !rgba) return -1;
+    OTexture *t = &s->tex[material];
+    free(t->pix);
+    t->pix = (uint8_t *)malloc((size_t)w * (size_t)h * 4);
+    memcpy(t->pix, rgba, (size_t)w * (size_t)h * 4);
+    t->w = w;
+    t->h = h;
+    return 0;
 }
 
 void orc_set_sample_tables(orc_scene *s, const double *camera_tab, int32_t n_camera,
@@ -977,6 +1012,33 @@ static void random_in_hemisphere(uint64_t stream, uint32_t *ctr, const float nor
     }
 }
 
+/* trace.go:154-187 getMaterialParameters: Kd, times the nearest texel of map_Kd
+ * when the material has one (texture.go:48-59 SampleUV / GetTexelCoordinates:
+ * no V flip, repeat wrap by uv - floor(uv), image.RGBA.At widened to 16 bits). */
+static void material_diffuse(const orc_scene *s, const OTriangle *t, float u, float v,
+                             float diffuse[3])
+{
+    const float *kd = s->kd + 3 * t->material;
+    diffuse[0] = kd[0]; diffuse[1] = kd[1]; diffuse[2] = kd[2];
+    const OTexture *tex = &s->tex[t->material];
+    if (!tex->pix) return;
+    const float w0 = 1.0f - u - v;
+    float tu = (t->tc[0][0] * w0 + t->tc[1][0] * u) + t->tc[2][0] * v;
+    float tv = (t->tc[0][1] * w0 + t->tc[1][1] * u) + t->tc[2][1] * v;
+    tu = tu - (float)floor((double)tu);
+    tv = tv - (float)floor((double)tv);
+    const float cx = tu * (float)tex->w, cy = tv * (float)tex->h;
+    const int32_t px = (int32_t)cx, py = (int32_t)cy;
+    float smp[3] = {0, 0, 0};                 /* At() outside the bounds: color.RGBA{} */
+    if (px >= 0 && py >= 0 && px < tex->w && py < tex->h) {
+        const uint8_t *p = tex->pix + 4 * ((size_t)py * (size_t)tex->w + (size_t)px);
+        const float k = (float)(1.0 / 65535.0);
+        for (int c = 0; c < 3; ++c) smp[c] = (float)((uint32_t)p[c] * 257u) * k;   /* c | c<<8 */
+    }
+    for (int c = 0; c < 3; ++c)
+        diffuse[c] = diffuse[c] * (float)orc_go_min(orc_go_max((double)smp[c], 0.0), 1.0);
+}
+
 static void trace(const orc_scene *s, const orc_pass *pass, const orc_light *light,
                   const float ro[3], const float rd[3], uint64_t path_index, float rgb[3],
                   orc_counters *c)
@@ -999,8 +1061,8 @@ static void trace(const orc_scene *s, const orc_pass *pass, const orc_light *lig
 
     for (;;) {
         float shading[3] = {0, 0, 0};
-        const float *kd = s->kd + 3 * res.tri->material;
-        float diffuse[3] = {kd[0], kd[1], kd[2]};
+        float diffuse[3];
+        material_diffuse(s, res.tri, res.u, res.v, diffuse);
         const float *normal = res.tri->normal;
 
         for (int i = 0; i < L; ++i) {

@@ -133,6 +133,12 @@ orc_scene *orc_scene_create(const float *verts, const int32_t *material,
                             const int32_t *group_index, int32_t n,
                             const float *kd, const uint8_t *is_light, int32_t m);
 void orc_scene_destroy(orc_scene *s);
+/* models/context.go:138-156: n*6 floats (uv0, uv1, uv2 per triangle, input order). */
+void orc_scene_set_texcoords(orc_scene *s, const float *uv);
+/* models/texture.go:24-46 + context.go:85-103: the image.RGBA behind one
+ * material's map_Kd (RGBA8 rows).  Returns 0, or -1 for a bad argument. */
+int32_t orc_scene_set_texture(orc_scene *s, int32_t material, const uint8_t *rgba,
+                              int32_t w, int32_t h);
 
 /* literal BuildBVH (bvh.go:31-114,146-212); returns node count */
 int32_t orc_build_bvh(orc_scene *s, int32_t use_bvh, int32_t max_leaf, int32_t max_depth);

@@ -76,6 +76,21 @@ void emul_trace_fast(const float *pairs, uint32_t fast_root, const float *tris, 
     }
 }
 
+// Optional texture inputs of the next emul_render calls (all NULL = untextured):
+// per-triangle UVs in array order, per-material texture slot, per-slot RGBA8
+// rows and (w, h).
+static const float *g_tri_uv = nullptr;
+static const int32_t *g_mat_tex = nullptr;
+static const uint8_t *const *g_tex_data = nullptr;
+static const int32_t *g_tex_dim = nullptr;
+void emul_set_textures(const float *tri_uv, const int32_t *mat_tex, const uint8_t *const *tex_data,
+                       const int32_t *tex_dim) {
+    g_tri_uv = tri_uv;
+    g_mat_tex = mat_tex;
+    g_tex_data = tex_data;
+    g_tex_dim = tex_dim;
+}
+
 // Serial path tracer over the device functions: the order of operations of
 // k_raygen / k_shade / k_finish / k_accumulate / k_resolve for one tile.
 void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t n_tris,
@@ -88,6 +103,10 @@ void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t
     s.tris = reinterpret_cast<const f4 *>(tris);
     s.tri_mat = tri_mat;
     s.kd = kd;
+    s.tri_uv = g_tri_uv;
+    s.mat_tex = g_mat_tex;
+    s.tex_data = g_tex_data;
+    s.tex_dim = g_tex_dim;
     s.cam_tab = cam_tab;
     s.light_tab = light_tab;
     s.n_nodes = n_nodes; s.n_tris = n_tris; s.n_cam = n_cam; s.n_light = n_light;

@@ -240,3 +240,45 @@ def test_ordered_records_layout(product_lib):
     leaf = (refs & 0x80000000) != 0
     assert (root & 0x80000000) == 0 and ((refs[leaf] >> 24) & 0x7F).sum() == 500
     assert (((refs[leaf] >> 24) & 0x7F) <= 4).all()
+
+
+def test_textured_render_bit_exact(product_lib, oracle, emul):
+    """map_Kd sampling of the device functions (material_diffuse) against the
+    oracle's getMaterialParameters: repeat wrap incl. negative coordinates, odd
+    texture sizes, textured and untextured materials side by side."""
+    sc = scenes.room_mesh(24, seed=0x5EED0002, total=1400)
+    n = sc["verts"].shape[0]
+    rng = np.random.default_rng(3)
+    uv = (rng.random((n, 6)) * 5.0 - 2.0).astype(np.float32)
+    tex_of_mat = np.full(sc["kd"].shape[0], -1, np.int32)
+    tex_of_mat[0], tex_of_mat[2] = 1, 0
+    images = [np.ascontiguousarray(rng.integers(0, 256, (9, 17, 4), dtype=np.uint8)),
+              np.ascontiguousarray(rng.integers(0, 256, (7, 5, 4), dtype=np.uint8))]
+    mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"],
+                    texcoords=uv, texture=tex_of_mat)
+    bvh = api.Bvh.build(mesh, True, 6, 24)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    cam_tab = api.default_sample_table(12345, 1)
+    light_tab = api.default_sample_table(100001, 2)
+    osc.set_sample_tables(cam_tab, light_tab)
+    osc.set_texcoords(uv)
+    for m, slot in enumerate(tex_of_mat):
+        if slot >= 0:
+            osc.set_texture(m, images[slot])
+    d = scenes.make_pass_dict(48, 32, sc["camera"], spp=2, bounces=2, light_samples=2,
+                              intensity=6.0, seed=9)
+    ref = osc.render_tile(oracle.pass_from_dict(d), want_radiance=True)
+    order = bvh.export()["order"]
+    tri_uv = np.ascontiguousarray(uv[order])                 # array order, like the flattened triangles
+    ptrs = (C.c_void_p * len(images))(*[im.ctypes.data for im in images])
+    dims = np.array([[im.shape[1], im.shape[0]] for im in images], np.int32)
+    emul.emul_set_textures(tri_uv.ctypes.data_as(C.c_void_p), tex_of_mat.ctypes.data_as(C.c_void_p),
+                           ptrs, dims.ctypes.data_as(C.c_void_p))
+    try:
+        accum, rad, rgba, rays = emul_render(emul, mesh, bvh, sc, api.pass_from_dict(d), cam_tab,
+                                             light_tab, 0, 2)
+    finally:
+        emul.emul_set_textures(None, None, None, None)
+    assert np.array_equal(accum.view(np.uint32).reshape(-1), ref["accum"].view(np.uint32).reshape(-1))
+    assert np.array_equal(rgba.reshape(-1), ref["rgba"].reshape(-1))
+    assert rays == ref["counters"]["rays"]

@@ -168,3 +168,40 @@ def test_fast_mode_image_agrees_with_reference_order(product_lib, oracle, gpu_de
     rel = np.abs(a["accum"] - b["accum"]) / np.maximum(np.abs(a["accum"]), 1e-6)
     assert (rel > 1e-5).any(axis=2).mean() < 1e-3
     assert abs(a["stats"]["rays"] - b["stats"]["rays"]) <= 1e-3 * a["stats"]["rays"]
+
+
+def test_textured_room_bit_exact(product_lib, oracle, gpu_device):
+    """map_Kd sampling (trace.go:161-181, texture.go:48-59) on every path vertex:
+    texture coordinates far outside [0,1) (repeat wrap, negative values), two
+    textures of odd sizes, an untextured material next to them."""
+    sc = scenes.room_mesh(48, seed=0x5EED0002, total=5200)
+    n = sc["verts"].shape[0]
+    rng = np.random.default_rng(11)
+    uv = (rng.random((n, 6)) * 5.0 - 2.0).astype(np.float32)
+    tex_of_mat = np.full(sc["kd"].shape[0], -1, np.int32)
+    tex_of_mat[0] = 1          # room walls
+    tex_of_mat[2] = 0          # height field
+    images = [rng.integers(0, 256, (9, 17, 4), dtype=np.uint8), rng.integers(0, 256, (7, 5, 4), dtype=np.uint8)]
+    mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"],
+                    texcoords=uv, texture=tex_of_mat)
+    bvh = api.Bvh.build(mesh, True, 6, 24)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    osc.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
+                          api.default_sample_table(100001, 0xC0FFEE02))
+    osc.set_texcoords(uv)
+    for slot, img in enumerate(images):
+        scene.set_texture(slot, img)
+    for m, slot in enumerate(tex_of_mat):
+        if slot >= 0:
+            osc.set_texture(m, images[slot])
+    d = scenes.make_pass_dict(128, 72, sc["camera"], spp=2, bounces=3, light_samples=2,
+                              intensity=6.0, seed=5)
+    out = scene.render_tile(api.pass_from_dict(d))
+    ref = osc.render_tile(oracle.pass_from_dict(d))
+    _compare(out, ref)
+    # the textures do change the picture
+    plain = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    plain.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
+                            api.default_sample_table(100001, 0xC0FFEE02))
+    assert not np.array_equal(plain.render_tile(oracle.pass_from_dict(d))["rgba"], ref["rgba"])
