@@ -40,6 +40,11 @@ WORKLOADS = {
                  bounces=4, light_samples=1, intensity=6.0,
                  label="1M-triangle room mesh (SAH BVH leaf 8), 3840x2160, 4 diffuse bounces, "
                        "1 light sample, 16x16 tiles"),
+    # the HBM-resident configuration: 0.5 GB of triangles + 0.2 GB of tree records per GPU
+    "cfg4": dict(grid=2236, tris=10_000_000, width=7680, height=4320, tiles=32, leaf=8, depth=48,
+                 bounces=4, light_samples=1, intensity=6.0, seed=0x5EED0004,
+                 label="10M-triangle room mesh (SAH BVH leaf 8), 7680x4320, 4 diffuse bounces, "
+                       "1 light sample, 32x32 tiles"),
     "small": dict(grid=96, tris=20_000, width=640, height=360, tiles=4, leaf=8, depth=40,
                   bounces=4, light_samples=1, intensity=6.0,
                   label="20k-triangle room mesh, 640x360 (functional check only)"),
@@ -152,7 +157,7 @@ def main():
 
     # ---- scene: generated and built on every rank (deterministic), resident per GPU
     t0 = time.perf_counter()
-    sc = scenes.room_mesh(wl["grid"], seed=0x5EED0002, total=wl["tris"])
+    sc = scenes.room_mesh(wl["grid"], seed=wl.get("seed", 0x5EED0002), total=wl["tris"])
     mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
     bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
     scene = api.Scene(mesh, bvh, local_rank)
@@ -280,6 +285,9 @@ def main():
         total_rays, kernel_ms = float(acc["rays"]), acc["kernel_ms"]
 
     if rank == 0:
+        # triangles 48 B + material 4 B each; one 32-B reference-order node and about one 64-B
+        # ordered record per node of the tree
+        scene_mb = (mesh.n_tris * 52 + bvh.n_nodes * 32 + bvh.n_nodes * 64) / 1e6
         value = total_rays / elapsed / 1e6
         # roofline of the traversal kernel: this rank's algorithmic bytes over the
         # time its traversal launches took (HIP events on the launch stream)
@@ -289,7 +297,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -313,12 +321,14 @@ def main():
                          "nodes_per_ray": round(nodes_per_ray, 2),
                          "tris_per_ray": round(tris_per_ray, 2),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
+                         "scene_mb": round(scene_mb, 1),
                          "note": "achieved = rays x bytes_per_ray (this kernel's own counted node and "
-                                 "triangle fetches) / traversal-launch time. The 64 MB scene is served "
-                                 "from L2 / Infinity Cache, so the algorithmic rate can exceed the HBM "
-                                 "peak; traffic = measured fabric bytes per launch (profiles/traffic.json). "
-                                 "Random 64-byte record gathers top out at 6.5 TB/s on a 10 MB table and "
-                                 "3.8 TB/s on a 64 MB table on this GPU (tools/ubench/gather.hip)"},
+                                 "triangle fetches) / traversal-launch time. A scene below 256 MB is "
+                                 "served from L2 / Infinity Cache, so the algorithmic rate can exceed the "
+                                 "HBM peak; traffic = measured fabric bytes per launch of this workload "
+                                 "(rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/traffic.json). Random 64-byte record gathers top out "
+                                 "at 6.5 TB/s on a 10 MB table, 3.8 TB/s on 64 MB and 3.5 TB/s on 1 GB "
+                                 "on this GPU (tools/ubench/gather.hip)"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(sc, bvh.export(), tables, wl, args, tile_list)
