@@ -163,7 +163,7 @@ rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *reco
     st = rt::flatten(*mesh, bvh->bvh, flat);
     if (st != RT_OK) return st;
     if (!flat.fast_ok) return fail(RT_ERR_INVALID, "tree does not fit the ordered-traversal encoding (more than 2^24-2 triangles or deeper than 60)");
-    *n_records = flat.pairs.size() / 16;
+    *n_records = flat.pairs.size() / rtc::kWideFloats;
     *root_ref = flat.fast_root;
     if (records) {
         if (capacity_records < *n_records) return fail(RT_ERR_INVALID, "records buffer too small");

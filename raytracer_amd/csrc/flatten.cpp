@@ -2,6 +2,7 @@
 // (models/bvh.go:13-29: BVHNode with child pointers and a Bounds pointer;
 // models/triangle.go:12-31: []*Triangle) into the two flat, 16-byte-aligned
 // record arrays the kernels read (layout: rt_core.h, DevScene).
+#include <cmath>
 #include <cstring>
 #include <limits>
 
@@ -12,35 +13,43 @@ namespace rt {
 
 namespace {
 
-// Child-pair records for the ordered traversal.  The reference's leaves hold
-// up to BVHMaxLeafSize triangles; here a leaf with more than kFastSplitLeaf is
-// cut in two by array position (the range is sorted along its parent's split
-// axis, bvh.go:73-76, so the halves are spatially separate) under synthetic
-// interior records with tight boxes, until every leaf is small: triangle tests
-// are the poorly-vectorised part of the traversal.  Array positions, and with
-// them hit ids and tie-breaking, are unchanged.  An empty leaf (the reference
-// can create one, bvh.go:94-100 with BVHMaxLeafSize 1) gets NaN bounds that no
-// ray enters.
-struct PairBuilder {
+// Records of the ordered traversal: a 4-wide tree collapsed from the
+// reference's binary one.
+//
+// Step 1, small leaves: the reference's leaves hold up to BVHMaxLeafSize
+// triangles; a leaf with more than kFastSplitLeaf is cut in two by array
+// position (the range is sorted along its parent's split axis, bvh.go:73-76, so
+// the halves are spatially separate) under synthetic interior nodes with tight
+// boxes, until every leaf is small: triangle tests are the poorly-vectorised
+// part of the traversal.  Array positions, and with them hit ids and
+// tie-breaking, are unchanged.
+//
+// Step 2, wide nodes: the traversal is bound by the number of dependent record
+// fetches and of 16-byte loads per ray, so each 64-byte record carries FOUR
+// child boxes: starting from a node's two children, the interior child with
+// the largest surface area is replaced by its own two children (in place, so
+// the reference's left-to-right order of the children is kept) until there are
+// four or only leaves are left.  The boxes are stored as 8-bit offsets from
+// the record's own frame (origin = lower corner of the union, one power-of-two
+// step per axis); lower planes are rounded down and upper planes up, and each
+// is checked with the very fused multiply-add the traversal decodes it with,
+// so a decoded box always CONTAINS the binary tree's box: the wide test passes
+// whenever the reference's box test does.  Empty leaves (the reference can
+// create one, bvh.go:94-100 with BVHMaxLeafSize 1) are dropped; unused slots
+// carry the reference kLeafBit (no triangles) and are never entered.
+struct WideBuilder {
+    struct BNode {            // binary node after step 1
+        float mn[3], mx[3];
+        int32_t left = -1, right = -1;   // indices into `bin`, -1 for a leaf
+        int32_t start = 0, count = 0;    // leaf: triangle range
+    };
     const rt_mesh &mesh;
     const Bvh &bvh;
     const std::vector<int32_t> &skip;
-    std::vector<float> &pairs;
-    const float nan_;
+    std::vector<float> &recs;
+    std::vector<BNode> bin;
+    int32_t max_wide_depth = 0;
 
-    uint32_t new_record() {
-        pairs.resize(pairs.size() + 16, 0.0f);
-        return (uint32_t)(pairs.size() / 16 - 1);
-    }
-    void set_child(uint32_t rec, int side, const float mn[3], const float mx[3], uint32_t ref) {
-        float *p = &pairs[(size_t)rec * 16 + (size_t)side * 6];
-        for (int k = 0; k < 3; ++k) {
-            p[2 * k] = mn[k];
-            p[2 * k + 1] = mx[k];
-        }
-        p = &pairs[(size_t)rec * 16];
-        p[12 + side] = rtc::i2f((int32_t)ref);
-    }
     // bounds of the triangles at array positions [start, start+count)
     void range_box(int32_t start, int32_t count, float mn[3], float mx[3]) const {
         for (int k = 0; k < 3; ++k) {
@@ -57,35 +66,164 @@ struct PairBuilder {
                 }
         }
     }
-    // reference to a triangle range
-    uint32_t leaf_ref(int32_t start, int32_t count) {
-        if (count <= rtc::kFastSplitLeaf)
-            return rtc::kLeafBit | ((uint32_t)count << 24) | (uint32_t)start;
-        const uint32_t rec = new_record();
+    // step 1 for one leaf range whose box is already known
+    int32_t small_leaf(int32_t start, int32_t count, const float mn[3], const float mx[3]) {
+        const int32_t id = (int32_t)bin.size();
+        bin.emplace_back();
+        std::memcpy(bin[(size_t)id].mn, mn, 12);
+        std::memcpy(bin[(size_t)id].mx, mx, 12);
+        if (count <= rtc::kFastSplitLeaf) {
+            bin[(size_t)id].start = start;
+            bin[(size_t)id].count = count;
+            return id;
+        }
         const int32_t half = count / 2;
-        float mn[3], mx[3];
-        const uint32_t l = leaf_ref(start, half);
-        range_box(start, half, mn, mx);
-        set_child(rec, 0, mn, mx, l);
-        const uint32_t r = leaf_ref(start + half, count - half);
-        range_box(start + half, count - half, mn, mx);
-        set_child(rec, 1, mn, mx, r);
+        float lmn[3], lmx[3];
+        range_box(start, half, lmn, lmx);
+        const int32_t l = small_leaf(start, half, lmn, lmx);
+        range_box(start + half, count - half, lmn, lmx);
+        const int32_t r = small_leaf(start + half, count - half, lmn, lmx);
+        bin[(size_t)id].left = l;
+        bin[(size_t)id].right = r;
+        return id;
+    }
+    // binary tree of the reference (preorder, skip links) -> `bin`, iteratively
+    int32_t import_tree() {
+        const int32_t nn = bvh.n_nodes;
+        std::vector<int32_t> id_of((size_t)nn, -1);
+        // parents before children is not needed: create nodes in reverse preorder so
+        // that both children exist when a parent is made
+        for (int32_t i = nn - 1; i >= 0; --i) {
+            const float *mn = &bvh.bmin[3 * (size_t)i], *mx = &bvh.bmax[3 * (size_t)i];
+            if (bvh.is_leaf[(size_t)i]) {
+                const int32_t start = bvh.start[(size_t)i];
+                const int32_t count = bvh.end[(size_t)i] - start + 1;
+                if (count <= 0) {
+                    const float nan_ = std::numeric_limits<float>::quiet_NaN();
+                    const float nn3[3] = {nan_, nan_, nan_};
+                    id_of[(size_t)i] = small_leaf(0, 0, nn3, nn3);   // NaN bounds fail every comparison of the slab test
+                } else {
+                    id_of[(size_t)i] = small_leaf(start, count, mn, mx);
+                }
+            } else {
+                const int32_t id = (int32_t)bin.size();
+                bin.emplace_back();
+                std::memcpy(bin[(size_t)id].mn, mn, 12);
+                std::memcpy(bin[(size_t)id].mx, mx, 12);
+                bin[(size_t)id].left = id_of[(size_t)i + 1];
+                bin[(size_t)id].right = id_of[(size_t)skip[(size_t)i + 1]];
+                id_of[(size_t)i] = id;
+            }
+        }
+        return id_of[0];
+    }
+    static float area(const BNode &n) {
+        const float d0 = n.mx[0] - n.mn[0], d1 = n.mx[1] - n.mn[1], d2 = n.mx[2] - n.mn[2];
+        return d0 * d1 + d0 * d2 + d1 * d2;
+    }
+    uint32_t leaf_ref(const BNode &n) const {
+        return rtc::kLeafBit | ((uint32_t)n.count << 24) | (uint32_t)n.start;
+    }
+    // step 2: the record of binary interior node `id`; returns its index
+    uint32_t emit(int32_t id, int32_t depth) {
+        if (depth > max_wide_depth) max_wide_depth = depth;
+        const uint32_t rec = (uint32_t)(recs.size() / rtc::kWideFloats);
+        recs.resize(recs.size() + rtc::kWideFloats, 0.0f);
+        int32_t kids[4] = {bin[(size_t)id].left, bin[(size_t)id].right, -1, -1};
+        int n = 2;
+        while (n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int i = 0; i < n; ++i) {
+                const BNode &c = bin[(size_t)kids[i]];
+                if (c.left < 0) continue;
+                float a = area(c);
+                if (!(a == a)) a = -1.0f;          // a NaN box (empty subtree) is opened last
+                if (best < 0 || a > best_area) {
+                    best = i;
+                    best_area = a;
+                }
+            }
+            if (best < 0) break;
+            const int32_t open = kids[best];
+            for (int i = n; i > best + 1; --i) kids[i] = kids[i - 1];
+            kids[best] = bin[(size_t)open].left;
+            kids[best + 1] = bin[(size_t)open].right;
+            ++n;
+        }
+        // drop empty leaves (NaN boxes)
+        {
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const BNode &c = bin[(size_t)kids[i]];
+                if (c.left < 0 && c.count <= 0) continue;
+                kids[m++] = kids[i];
+            }
+            n = m;
+        }
+        // frame: lower corner of the union and a power-of-two step per axis
+        float origin[3], step[3];
+        uint8_t qlo[4][3], qhi[4][3];
+        for (int a = 0; a < 3; ++a) {
+            float lo = std::numeric_limits<float>::max(), hi = -std::numeric_limits<float>::max();
+            for (int i = 0; i < n; ++i) {
+                const BNode &c = bin[(size_t)kids[i]];
+                if (c.mn[a] < lo) lo = c.mn[a];
+                if (c.mx[a] > hi) hi = c.mx[a];
+            }
+            if (n == 0) { lo = 0; hi = 0; }
+            origin[a] = lo;
+            int e;
+            const float ext = hi - lo;
+            // smallest power of two s with 255 * s >= ext (rounded up generously), at least a denormal-safe floor
+            (void)std::frexp(ext > 0 ? ext / 255.0f : 0.0f, &e);
+            if (!(ext > 0)) e = -120;
+            if (e < -120) e = -120;
+            for (;; ++e) {
+                const float s = std::ldexp(1.0f, e);
+                bool ok = true;
+                for (int i = 0; i < n && ok; ++i) {
+                    const BNode &c = bin[(size_t)kids[i]];
+                    // lower plane: largest q with decode(q) <= bound
+                    float x = std::floor((c.mn[a] - lo) / s);
+                    if (x < 0) x = 0;
+                    if (x > 255) x = 255;
+                    int q = (int)x;
+                    while (q > 0 && std::fmaf((float)q, s, lo) > c.mn[a]) --q;
+                    if (std::fmaf((float)q, s, lo) > c.mn[a]) ok = false;
+                    qlo[i][a] = (uint8_t)q;
+                    // upper plane: smallest q with decode(q) >= bound
+                    x = std::ceil((c.mx[a] - lo) / s);
+                    if (x < 0) x = 0;
+                    if (x > 255) { ok = false; x = 255; }
+                    q = (int)x;
+                    while (q < 255 && std::fmaf((float)q, s, lo) < c.mx[a]) ++q;
+                    if (std::fmaf((float)q, s, lo) < c.mx[a]) ok = false;
+                    qhi[i][a] = (uint8_t)q;
+                }
+                if (ok) { step[a] = s; break; }
+            }
+        }
+        float *p = &recs[(size_t)rec * rtc::kWideFloats];
+        p[0] = origin[0]; p[1] = origin[1]; p[2] = origin[2];
+        p[3] = step[0]; p[4] = step[1]; p[5] = step[2];
+        uint32_t planes[6] = {0, 0, 0, 0, 0, 0};   // lo.x lo.y lo.z hi.x hi.y hi.z, child c in byte c
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) {
+                planes[a] |= (uint32_t)qlo[i][a] << (8 * i);
+                planes[3 + a] |= (uint32_t)qhi[i][a] << (8 * i);
+            }
+        for (int j = 0; j < 6; ++j) p[6 + j] = rtc::i2f((int32_t)planes[j]);
+        for (int i = 0; i < 4; ++i) {
+            uint32_t ref = rtc::kLeafBit;            // unused slot: no triangles, never entered
+            if (i < n) {
+                const BNode c = bin[(size_t)kids[i]];
+                ref = c.left < 0 ? leaf_ref(c) : emit(kids[i], depth + 1);
+            }
+            recs[(size_t)rec * rtc::kWideFloats + 12 + (size_t)i] = rtc::i2f((int32_t)ref);
+        }
         return rec;
     }
-    uint32_t child_ref(int32_t node, float mn[3], float mx[3]) {
-        std::memcpy(mn, &bvh.bmin[3 * (size_t)node], 12);
-        std::memcpy(mx, &bvh.bmax[3 * (size_t)node], 12);
-        if (!bvh.is_leaf[(size_t)node]) return record_of[(size_t)node];
-        const int32_t start = bvh.start[(size_t)node];
-        const int32_t count = bvh.end[(size_t)node] - start + 1;
-        if (count <= 0) {
-            // NaN bounds fail every comparison of the slab test
-            for (int k = 0; k < 3; ++k) { mn[k] = nan_; mx[k] = nan_; }
-            return rtc::kLeafBit;   // count 0
-        }
-        return leaf_ref(start, count);
-    }
-    std::vector<uint32_t> record_of;   // interior node -> record index
 };
 
 void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t> &skip, FlatScene &out) {
@@ -93,28 +231,23 @@ void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t>
     out.fast_ok = false;
     out.fast_root = 0;
     if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
-    PairBuilder b{mesh, bvh, skip, out.pairs, std::numeric_limits<float>::quiet_NaN(), {}};
-    const int32_t nn = bvh.n_nodes;
-    b.record_of.assign((size_t)nn, 0);
-    for (int32_t i = 0; i < nn; ++i)
-        if (!bvh.is_leaf[(size_t)i]) b.record_of[(size_t)i] = b.new_record();
-    float mn[3], mx[3];
-    for (int32_t i = 0; i < nn; ++i) {
-        if (bvh.is_leaf[(size_t)i]) continue;
-        const int32_t l = i + 1, r = skip[(size_t)l];
-        const uint32_t rec = b.record_of[(size_t)i];
-        const uint32_t lref = b.child_ref(l, mn, mx);
-        b.set_child(rec, 0, mn, mx, lref);
-        const uint32_t rref = b.child_ref(r, mn, mx);
-        b.set_child(rec, 1, mn, mx, rref);
+    WideBuilder b{mesh, bvh, skip, out.pairs, {}, 0};
+    b.bin.reserve((size_t)bvh.n_nodes * 2);
+    const int32_t root = b.import_tree();
+    const WideBuilder::BNode &rn = b.bin[(size_t)root];
+    if (rn.left < 0) {
+        if (rn.count <= 0) return;      // a tree whose root is an empty leaf has nothing to traverse in order
+        out.fast_root = b.leaf_ref(rn); // the root is entered without a box test
+        out.pairs.resize(rtc::kWideFloats, 0.0f);
+    } else {
+        out.fast_root = b.emit(root, 1);
     }
-    out.fast_root = b.child_ref(0, mn, mx);   // the root is entered without a box test
-    if (out.fast_root == rtc::kLeafBit) {     // a tree whose root is an empty leaf has nothing to traverse in order
+    // every level can leave three entries on a lane's stack
+    if (3 * b.max_wide_depth > rtc::kFastStackEntries) {
         out.pairs.clear();
         out.fast_root = 0;
         return;
     }
-    if (out.pairs.empty()) out.pairs.resize(16, 0.0f);
     out.fast_ok = true;
 }
 

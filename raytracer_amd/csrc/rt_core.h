@@ -25,6 +25,7 @@
 namespace rtc {
 
 constexpr float kF32Max = 3.40282346638528859811704183484516925440e+38f;
+constexpr float kF32Inf = __builtin_huge_valf();
 
 struct alignas(16) f4 {
     float x, y, z, w;
@@ -63,13 +64,16 @@ struct DevScene {
     const int32_t *mat_tex;     // n_materials texture slot or -1 (nullptr: none)
     const uint8_t *const *tex_data;   // per slot RGBA8 rows
     const int32_t *tex_dim;     // per slot (w, h)
-    // Ordered-traversal view of the same tree (fast mode): one 64-byte record
-    // per interior node holding BOTH children's boxes and references,
-    //   [0] = (L.min.x, L.max.x, L.min.y, L.max.y) [1] = (L.min.z, L.max.z, R.min.x, R.max.x)
-    //   [2] = (R.min.y, R.max.y, R.min.z, R.max.z)   [3] = (bits L.ref, bits R.ref, 0, 0)
-    // (min and max of one axis side by side: the two slab distances of an axis
-    // come out of one packed subtract and one packed multiply)
-    // ref: interior -> record index; leaf -> kLeafBit | count << 24 | first triangle.
+    // Ordered-traversal view of the same tree (fast mode): 4-wide records of 64
+    // bytes (16 dwords):
+    //   [0..2]  origin of the record's frame (lower corner of the children's union)
+    //   [3..5]  step per axis (a power of two)
+    //   [6..8]  lower planes x, y, z: child c's 8-bit offset in byte c
+    //   [9..11] upper planes x, y, z, likewise
+    //   [12..15] child refs: interior -> record index; leaf -> kLeafBit | count << 24
+    //            | first triangle; unused slot -> kLeafBit (count 0)
+    // A plane decodes as fma(offset, step, origin); decoded boxes contain the
+    // binary tree's boxes (lower planes rounded down, upper planes up).
     const f4 *pairs;
     uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
     int32_t fast_ok;            // 0: tree does not fit the fast encoding
@@ -83,6 +87,8 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefDone = 0xFFFFFFFFu;   // empty-stack marker (count 127, start 2^24-1 is never built)
 constexpr int32_t kFastMaxLeaf = 126;
 constexpr int32_t kFastSplitLeaf = 4;   // larger leaves are cut in two for the ordered traversal
+constexpr int32_t kWideFloats = 16;     // one ordered-traversal record: frame + 4 quantised child boxes + 4 refs = 64 bytes
+constexpr int32_t kFastStackEntries = 96;   // per-ray stack of the ordered traversal
 constexpr int32_t kFastMaxTris = (1 << 24) - 2;
 
 // ---------------------------------------------------------------------------
@@ -207,46 +213,73 @@ RT_HD void traverse_ref_order(const DevScene &s, const Ray<Real> &r, Hit<Real> &
 // closer hit exists.  Box slabs use the reference's (bound - origin) * invDir;
 // the triangle test is tri_test() unchanged, so t, u, v of a given triangle are
 // bit-identical to the reference order's.
+// Sorts four (entry distance, child ref) pairs by distance, ascending, with a
+// fixed five-exchange network; an exchange happens only on a strictly smaller
+// distance, so of two equal children the earlier slot stays first where the
+// network compares them directly.  Missed children carry +inf and end up last.
+RT_HD void wide_sort4(float key[4], uint32_t ref[4]) {
+#define RT_CE(a, b)                                    \
+    do {                                               \
+        const bool sw = key[b] < key[a];               \
+        const float ka = sw ? key[b] : key[a];         \
+        const float kb = sw ? key[a] : key[b];         \
+        const uint32_t ra = sw ? ref[b] : ref[a];      \
+        const uint32_t rb = sw ? ref[a] : ref[b];      \
+        key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; \
+    } while (0)
+    RT_CE(0, 1);
+    RT_CE(2, 3);
+    RT_CE(0, 2);
+    RT_CE(1, 3);
+    RT_CE(1, 2);
+#undef RT_CE
+}
+
 template <bool COUNT>
 RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &h, Counters *c) {
-    uint32_t stack_ref[64];
-    float stack_t[64];
+    uint32_t stack_ref[kFastStackEntries];
+    float stack_t[kFastStackEntries];
     int32_t sp = 0;
     uint32_t cur = s.fast_root;
     for (;;) {
         while ((cur & kLeafBit) == 0) {
-            const f4 *q = s.pairs + 4 * (size_t)cur;
-            const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) { c->nodes_visited++; c->box_tests += 2; }
-            const float lx0 = (q0.x - r.ox) * r.ix, lx1 = (q0.y - r.ox) * r.ix;
-            const float ly0 = (q0.z - r.oy) * r.iy, ly1 = (q0.w - r.oy) * r.iy;
-            const float lz0 = (q1.x - r.oz) * r.iz, lz1 = (q1.y - r.oz) * r.iz;
-            const float rx0 = (q1.z - r.ox) * r.ix, rx1 = (q1.w - r.ox) * r.ix;
-            const float ry0 = (q2.x - r.oy) * r.iy, ry1 = (q2.y - r.oy) * r.iy;
-            const float rz0 = (q2.z - r.oz) * r.iz, rz1 = (q2.w - r.oz) * r.iz;
-            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
-            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
-            const bool hl = ln <= lf && ln < h.t && lf > 0;
-            const bool hr = rn <= rf && rn < h.t && rf > 0;
-            const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
-            if (hl && hr) {
-                const bool left_first = ln <= rn;
-                stack_ref[sp] = left_first ? rref : lref;
-                stack_t[sp] = left_first ? rn : ln;
-                sp++;
-                cur = left_first ? lref : rref;
-            } else if (hl) {
-                cur = lref;
-            } else if (hr) {
-                cur = rref;
-            } else {
+            const float *q = reinterpret_cast<const float *>(s.pairs) + (size_t)kWideFloats * (size_t)cur;
+            if (COUNT) { c->nodes_visited++; c->box_tests += 4; }
+            float key[4];
+            uint32_t ref[4];
+            int n_hit = 0;
+            for (int k = 0; k < 4; ++k) {
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    const uint32_t pl = (uint32_t)f2i(q[6 + a]), ph = (uint32_t)f2i(q[9 + a]);
+                    lo[a] = fmaf((float)((pl >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
+                    hi[a] = fmaf((float)((ph >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
+                }
+                const float x0 = (lo[0] - r.ox) * r.ix, x1 = (hi[0] - r.ox) * r.ix;
+                const float y0 = (lo[1] - r.oy) * r.iy, y1 = (hi[1] - r.oy) * r.iy;
+                const float z0 = (lo[2] - r.oz) * r.iz, z1 = (hi[2] - r.oz) * r.iz;
+                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                ref[k] = (uint32_t)f2i(q[12 + k]);
+                const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;
+                key[k] = hit ? tn : kF32Inf;
+                n_hit += hit ? 1 : 0;
+            }
+            wide_sort4(key, ref);
+            if (n_hit == 0) {
                 cur = kRefDone;
                 while (sp > 0) {
                     sp--;
                     if (stack_t[sp] < h.t) { cur = stack_ref[sp]; break; }
                 }
+            } else {
+                // farthest first, so that the nearest of the rest is popped first
+                for (int k = n_hit - 1; k >= 1; --k) {
+                    stack_ref[sp] = ref[k];
+                    stack_t[sp] = key[k];
+                    sp++;
+                }
+                cur = ref[0];
             }
         }
         if (cur == kRefDone) return;

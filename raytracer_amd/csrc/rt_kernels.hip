@@ -249,7 +249,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // traversal except where the reference's own box test prunes a triangle it
 // would accept.
 // ---------------------------------------------------------------------------
-constexpr int kStackTotal = 64;
+constexpr int kStackTotal = kFastStackEntries;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <bool COUNT, int kStackLds>
@@ -353,31 +353,49 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (!descending) continue;
             const f4 *q = s.pairs + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) { c_nodes++; c_box += 2; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
-            // slabs with the reference's arithmetic, (bound - origin) * invDir; the
-            // record keeps an axis' two bounds side by side so that each pair is
-            // one packed subtract and one packed multiply
-            const f2 lx = (f2{q0.x, q0.y} - f2{r.ox, r.ox}) * f2{r.ix, r.ix};
-            const f2 ly = (f2{q0.z, q0.w} - f2{r.oy, r.oy}) * f2{r.iy, r.iy};
-            const f2 lz = (f2{q1.x, q1.y} - f2{r.oz, r.oz}) * f2{r.iz, r.iz};
-            const f2 rx = (f2{q1.z, q1.w} - f2{r.ox, r.ox}) * f2{r.ix, r.ix};
-            const f2 ry = (f2{q2.x, q2.y} - f2{r.oy, r.oy}) * f2{r.iy, r.iy};
-            const f2 rz = (f2{q2.z, q2.w} - f2{r.oz, r.oz}) * f2{r.iz, r.iz};
-            const float ln = fmaxf(fmaxf(fminf(lx.x, lx.y), fminf(ly.x, ly.y)), fminf(lz.x, lz.y));
-            const float lf = fminf(fminf(fmaxf(lx.x, lx.y), fmaxf(ly.x, ly.y)), fmaxf(lz.x, lz.y));
-            const float rn = fmaxf(fmaxf(fminf(rx.x, rx.y), fminf(ry.x, ry.y)), fminf(rz.x, rz.y));
-            const float rf = fminf(fminf(fmaxf(rx.x, rx.y), fmaxf(ry.x, ry.y)), fmaxf(rz.x, rz.y));
-            const bool hl = ln <= lf && ln < h.t && lf > 0;
-            const bool hr = rn <= rf && rn < h.t && rf > 0;
-            const uint32_t lref = (uint32_t)f2i(q3.x), rref = (uint32_t)f2i(q3.y);
-            if (hl && hr) {
-                const bool left_first = ln <= rn;
-                push(left_first ? rref : lref, left_first ? rn : ln);
-                stand_on(left_first ? lref : rref);
-            } else if (hl || hr) {
-                stand_on(hl ? lref : rref);
-            } else {
+            if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
+            // frame of the record, then per child: decode the six planes with one
+            // fused multiply-add each (byte -> float conversions are single
+            // instructions), and the reference's slab arithmetic
+            // (bound - origin) * invDir on the decoded planes, two planes per
+            // packed instruction
+            const f2 fo_x{q0.x, q0.x}, fo_y{q0.y, q0.y}, fo_z{q0.z, q0.z};
+            const f2 fs_x{q0.w, q0.w}, fs_y{q1.x, q1.x}, fs_z{q1.y, q1.y};
+            const uint32_t plx = (uint32_t)f2i(q1.z), ply = (uint32_t)f2i(q1.w), plz = (uint32_t)f2i(q2.x);
+            const uint32_t phx = (uint32_t)f2i(q2.y), phy = (uint32_t)f2i(q2.z), phz = (uint32_t)f2i(q2.w);
+            const f2 ox{r.ox, r.ox}, oy{r.oy, r.oy}, oz{r.oz, r.oz};
+            const f2 ix{r.ix, r.ix}, iy{r.iy, r.iy}, iz{r.iz, r.iz};
+            float key[4];
+            uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
+            int n_hit = 0;
+#define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
+#define RT_SLAB(k)                                                                          \
+            {                                                                               \
+                const f2 bx = __builtin_elementwise_fma(f2{RT_BYTE(plx, k), RT_BYTE(phx, k)}, fs_x, fo_x); \
+                const f2 by = __builtin_elementwise_fma(f2{RT_BYTE(ply, k), RT_BYTE(phy, k)}, fs_y, fo_y); \
+                const f2 bz = __builtin_elementwise_fma(f2{RT_BYTE(plz, k), RT_BYTE(phz, k)}, fs_z, fo_z); \
+                const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
+                const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y)); \
+                const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y)); \
+                const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;      \
+                key[k] = hit ? tn : kF32Inf;                                                \
+                n_hit += hit ? 1 : 0;                                                       \
+            }
+            RT_SLAB(0)
+            RT_SLAB(1)
+            RT_SLAB(2)
+            RT_SLAB(3)
+#undef RT_SLAB
+#undef RT_BYTE
+            wide_sort4(key, ref);
+            if (n_hit == 0) {
                 alive = pop_next();
+            } else {
+                // farthest first, so that the nearest of the rest is popped first
+                if (n_hit > 3) push(ref[3], key[3]);
+                if (n_hit > 2) push(ref[2], key[2]);
+                if (n_hit > 1) push(ref[1], key[1]);
+                stand_on(ref[0]);
             }
         }
         // phase B: lanes holding a leaf test its triangles in array order, two

@@ -212,32 +212,66 @@ def test_ordered_traversal_finds_the_same_hits(product_lib, oracle, emul, n, lea
         assert 56 * int(cnt[1]) + 48 * int(cnt[3]) < 56 * c["nodes_visited"] + 48 * c["tris_fetched"]
 
 
+def _decode_wide(rec):
+    """Child boxes of 64-byte ordered-traversal records: (n, 4, 3) lower and
+    upper planes, decoded like the traversal does, fma(offset, step, origin)."""
+    origin = rec[:, 0:3].astype(np.float64)
+    step = rec[:, 3:6].astype(np.float64)
+    planes = rec[:, 6:12].view(np.uint32)
+    k = np.arange(4, dtype=np.uint32)[None, :, None]
+    lo_q = (planes[:, None, 0:3] >> (8 * k)) & 0xFF
+    hi_q = (planes[:, None, 3:6] >> (8 * k)) & 0xFF
+    # offset * step is exact in float64 (8 bits x 24 bits), so rounding the sum once to
+    # float32 equals the fused multiply-add
+    lo = (lo_q * step[:, None, :] + origin[:, None, :]).astype(np.float32)
+    hi = (hi_q * step[:, None, :] + origin[:, None, :]).astype(np.float32)
+    return lo, hi
+
+
 def test_ordered_records_layout(product_lib):
     sc = scenes.soup(300, seed=2)
     bvh = api.Bvh.build(product_mesh(sc), True, 6, 16)
     e = bvh.export()
     rec, root = bvh.flatten_ordered()
-    refs = rec[:, 12:14].view(np.uint32)
-    leaf = (refs & 0x80000000) != 0
+    assert rec.shape[1] == 16 and root == 0
+    refs = rec[:, 12:16].view(np.uint32)
+    unused = refs == 0x80000000                       # empty slot: leaf bit, count 0
+    leaf = ((refs & 0x80000000) != 0) & ~unused
     counts = (refs[leaf] >> 24) & 0x7F
     starts = refs[leaf] & 0xFFFFFF
-    # leaves of more than 4 triangles are cut in two by array position under
-    # synthetic records: the small leaves tile the array, every reference leaf
-    # start is among theirs, and each cut added one record
-    assert root == 0 and counts.sum() == 300 and counts.max() <= 4 and counts.min() >= 1
+    # leaves of more than 4 triangles are cut in two by array position: the small
+    # leaves tile the array and every reference leaf start is among theirs
+    assert counts.sum() == 300 and counts.max() <= 4 and counts.min() >= 1
     order = np.argsort(starts)
     assert np.array_equal(np.cumsum(counts[order]) - counts[order], starts[order])
     assert set(e["start"][e["is_leaf"] == 1].tolist()) <= set(starts.tolist())
-    n_ref_leaves = int((e["is_leaf"] == 1).sum())
-    assert rec.shape[0] == int((e["is_leaf"] == 0).sum()) + (len(starts) - n_ref_leaves)
-    assert np.all(refs[~leaf] < rec.shape[0])
-    # root record holds the boxes of nodes 1 and its sibling
-    assert np.array_equal(rec[0, 0:6:2], e["bmin"][1]) and np.array_equal(rec[0, 1:6:2], e["bmax"][1])
-    # oversized leaves are chained through synthetic records
+    interior = ~leaf & ~unused
+    assert np.all(refs[interior] < rec.shape[0])
+    # every record but the root is referenced exactly once; used slots come first
+    assert sorted(refs[interior].tolist()) == list(range(1, rec.shape[0]))
+    assert (np.diff(unused.astype(int), axis=1) >= 0).all()
+    # steps are powers of two; decoded leaf boxes contain their triangles
+    step = rec[:, 3:6]
+    m, _ = np.frexp(step)
+    assert (m == 0.5).all()
+    lo, hi = _decode_wide(rec)
+    v = sc["verts"].reshape(-1, 3, 3)[e["order"]]
+    for r, c in zip(*np.nonzero(leaf)):
+        s0, n0 = int(refs[r, c] & 0xFFFFFF), int((refs[r, c] >> 24) & 0x7F)
+        tri = v[s0:s0 + n0].reshape(-1, 3)
+        assert (lo[r, c] <= tri.min(axis=0)).all() and (hi[r, c] >= tri.max(axis=0)).all()
+        # ... and are not looser than one step per side
+        assert (tri.min(axis=0) - lo[r, c] <= step[r] * 1.001).all()
+        assert (hi[r, c] - tri.max(axis=0) <= step[r] * 1.001).all()
+    # the root record's children cover the root box of the reference tree
+    used0 = ~unused[0]
+    assert (lo[0][used0].min(axis=0) <= e["bmin"][0]).all() and (hi[0][used0].max(axis=0) >= e["bmax"][0]).all()
+    assert np.array_equal(rec[0, 0:3], e["bmin"][0])
+    # a tree that is one big leaf becomes a tree of small leaves
     big = api.Bvh.build(product_mesh(scenes.soup(500, seed=3)), False, 6, 16)
     rec, root = big.flatten_ordered()
-    refs = rec[:, 12:14].view(np.uint32)
-    leaf = (refs & 0x80000000) != 0
+    refs = rec[:, 12:16].view(np.uint32)
+    leaf = ((refs & 0x80000000) != 0) & (refs != 0x80000000)
     assert (root & 0x80000000) == 0 and ((refs[leaf] >> 24) & 0x7F).sum() == 500
     assert (((refs[leaf] >> 24) & 0x7F) <= 4).all()
 
