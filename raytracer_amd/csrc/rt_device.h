@@ -65,10 +65,10 @@ struct Scene {
     size_t max_paths_in_flight = (size_t)1 << 25;
     // launch tuning (defaults chosen by measurement; overridable for experiments)
     int tune_stack = 8;           // LDS stack entries per lane of the fast kernel
-    int tune_refill = 60;         // refill idle lanes once fewer than this many are active
+    int tune_refill = 0;          // refill idle lanes once fewer than this many are active (0 = per-kernel default)
     int tune_blocks_per_cu = 8;   // persistent grid size
-    int tune_leaf_min = 8;        // fast kernel: leave the leaf phase below this many lanes in a leaf
-    int tune_descend_min = 24;    // fast kernel: leave the descent phase below this many descending lanes
+    int tune_leaf_min = 0;        // leave the leaf phase below this many lanes in a leaf (0 = per-kernel default)
+    int tune_descend_min = 0;     // leave the descent phase below this many descending lanes (0 = per-kernel default)
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;

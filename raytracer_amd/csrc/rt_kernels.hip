@@ -873,18 +873,23 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const DevScene d = dev_view(sc);
     const dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
+    // wave scheduling thresholds (refill, descend_min, leaf_min): measured optimum per kernel
+    const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_pairs;
+    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 60 : 48);
+    const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 32 : 24);
+    const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 16 : 8);
     switch (mode) {
     case RT_MODE_FAST_F32:
         if (sc.d_pairs) {
-            const int rb = sc.tune_refill;
+            const int rb = t_refill;
             if (d_counters) {
-                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min);
+                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
             } else {
                 switch (sc.tune_stack) {
-                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
-                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
-                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
-                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, sc.tune_descend_min, sc.tune_leaf_min); break;
+                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 }
             }
             break;
@@ -893,15 +898,15 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         [[fallthrough]];
     case RT_MODE_STRICT_F32:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
+            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
         else
-            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
+            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
         break;
     case RT_MODE_FP64:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
+            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
         else
-            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.tune_refill, sc.tune_descend_min, sc.tune_leaf_min);
+            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
         break;
     default:
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
