@@ -107,11 +107,15 @@ void rt_free(void *p);
 rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float *tris,
                      int32_t *tri_material);
 
-/* The second flat view used by RT_MODE_FAST_F32: one 64-byte record per
- * interior node holding both children's boxes and references, 16 floats each:
- * (L.min.x, L.max.x, L.min.y, L.max.y, L.min.z, L.max.z, then the same six
- * for R, bits L.ref, bits R.ref, 0, 0);
- * ref = record index, or for a leaf 0x80000000 | count << 24 | first triangle.
+/* The second flat view used by RT_MODE_FAST_F32: a 4-wide tree collapsed from
+ * the binary one (leaves of more than two triangles cut in two by array
+ * position first), one 64-byte record of 16 dwords per interior node:
+ *   [0..2]  origin of the record's frame, [3..5] step per axis (a power of two),
+ *   [6..8]  lower planes x, y, z -- child c's 8-bit offset in byte c,
+ *   [9..11] upper planes x, y, z likewise (a plane is fma(offset, step, origin);
+ *           decoded boxes contain the binary tree's boxes),
+ *   [12..15] child refs = record index, or for a leaf
+ *           0x80000000 | count << 24 | first triangle; unused slot = 0x80000000.
  * Call with records == NULL to get the count.  *root_ref is the ref traversal
  * starts from. */
 rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *records,
