@@ -175,7 +175,7 @@ rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_
                                int32_t width, int32_t height);
 /* Upper bound on camera samples traced together by the tile renderer (sets
  * the size of its device workspace, about 370 bytes per sample at 4 bounces
- * and 1 light sample); default 33554432. */
+ * and 1 light sample); default 67108864. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
 /* Launch parameters of the traversal kernels, for experiments: entries of the
  * per-lane stack kept in LDS (8, 12, 16 or 24; deeper entries spill), the

@@ -62,7 +62,7 @@ struct Scene {
     std::vector<uint8_t *> tex_ptrs;
     std::vector<int32_t> tex_dims;
     // path-tracing workspace (grow-only)
-    size_t max_paths_in_flight = (size_t)1 << 25;
+    size_t max_paths_in_flight = (size_t)1 << 26;
     // launch tuning (defaults chosen by measurement; overridable for experiments)
     int tune_stack = 8;           // LDS stack entries per lane of the fast kernel
     int tune_refill = 0;          // refill idle lanes once fewer than this many are active (0 = per-kernel default)
