@@ -5,6 +5,7 @@
 #pragma once
 
 #include <cctype>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -242,10 +243,9 @@ class Parser {
             const char *q = p_;
             if (*q == '-') ++q;
             while (q < end_ && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) ++q;
-            std::string tmp(p_, q);
-            char *endp = nullptr;
-            out.num = std::strtod(tmp.c_str(), &endp);
-            if (endp == tmp.c_str() || *endp != '\0') return fail("bad number");
+            // from_chars takes no leading '+', like JSON; it must consume the whole token
+            const auto r = std::from_chars(p_, q, out.num);
+            if (r.ec != std::errc() || r.ptr != q) return fail("bad number");
             out.kind = Value::Number;
             p_ = q;
             return true;
@@ -259,18 +259,25 @@ inline bool parse(const char *s, size_t n, Value &out, std::string &err) {
     return p.parse(out, err);
 }
 
-// shortest decimal text that round-trips a float32
+// Shortest decimal text that round-trips a float32, in the form Go's
+// encoding/json writes it (strconv 'f' format, 'e' below 1e-6 and from 1e21
+// on, with "e-09" shortened to "e-9").
 inline void append_f32(std::string &out, float f) {
     if (!std::isfinite(f)) {   // encoding/json refuses these; keep the output parseable
         out += "0";
         return;
     }
-    char buf[40];
-    for (int prec = 1; prec <= 9; ++prec) {
-        std::snprintf(buf, sizeof buf, "%.*g", prec, (double)f);
-        if (std::strtof(buf, nullptr) == f) break;
+    char buf[64];
+    const float a = std::fabs(f);
+    const bool sci = a != 0.0f && (a < 1e-6f || a >= 1e21f);
+    auto r = std::to_chars(buf, buf + sizeof buf, f,
+                           sci ? std::chars_format::scientific : std::chars_format::fixed);
+    size_t n = (size_t)(r.ptr - buf);
+    if (sci && n >= 4 && buf[n - 4] == 'e' && buf[n - 3] == '-' && buf[n - 2] == '0') {
+        buf[n - 2] = buf[n - 1];
+        --n;
     }
-    out += buf;
+    out.append(buf, n);
 }
 
 inline void append_escaped(std::string &out, const std::string &s) {
