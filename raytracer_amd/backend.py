@@ -72,6 +72,10 @@ class Backend:
         if mode is not None:
             check(_lib().rtb_set_mode(self._h, mode))
 
+    def set_mode(self, mode):
+        """Traversal mode of the render calls (api.MODE_*)."""
+        check(_lib().rtb_set_mode(self._h, mode))
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib().rtb_destroy(self._h)
