@@ -248,18 +248,24 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
             float key[4];
             uint32_t ref[4];
             int n_hit = 0;
+            // near / far plane words per axis, chosen by the sign of the inverse direction
+            const float inv[3] = {r.ix, r.iy, r.iz}, org[3] = {r.ox, r.oy, r.oz};
+            uint32_t pn[3], pf[3];
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t pl = (uint32_t)f2i(q[6 + a]), ph = (uint32_t)f2i(q[9 + a]);
+                pn[a] = inv[a] < 0 ? ph : pl;
+                pf[a] = inv[a] < 0 ? pl : ph;
+            }
             for (int k = 0; k < 4; ++k) {
-                float lo[3], hi[3];
+                float tna[3], tfa[3];
                 for (int a = 0; a < 3; ++a) {
-                    const uint32_t pl = (uint32_t)f2i(q[6 + a]), ph = (uint32_t)f2i(q[9 + a]);
-                    lo[a] = fmaf((float)((pl >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
-                    hi[a] = fmaf((float)((ph >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
+                    const float bn = fmaf((float)((pn[a] >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
+                    const float bf = fmaf((float)((pf[a] >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
+                    tna[a] = (bn - org[a]) * inv[a];
+                    tfa[a] = (bf - org[a]) * inv[a];
                 }
-                const float x0 = (lo[0] - r.ox) * r.ix, x1 = (hi[0] - r.ox) * r.ix;
-                const float y0 = (lo[1] - r.oy) * r.iy, y1 = (hi[1] - r.oy) * r.iy;
-                const float z0 = (lo[2] - r.oz) * r.iz, z1 = (hi[2] - r.oz) * r.iz;
-                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                const float tn = fmaxf(fmaxf(tna[0], tna[1]), tna[2]);
+                const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);
                 ref[k] = (uint32_t)f2i(q[12 + k]);
                 const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;
                 key[k] = hit ? tn : kF32Inf;

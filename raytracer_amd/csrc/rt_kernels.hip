@@ -361,8 +361,16 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // packed instruction
             const f2 fo_x{q0.x, q0.x}, fo_y{q0.y, q0.y}, fo_z{q0.z, q0.z};
             const f2 fs_x{q0.w, q0.w}, fs_y{q1.x, q1.x}, fs_z{q1.y, q1.y};
-            const uint32_t plx = (uint32_t)f2i(q1.z), ply = (uint32_t)f2i(q1.w), plz = (uint32_t)f2i(q2.x);
-            const uint32_t phx = (uint32_t)f2i(q2.y), phy = (uint32_t)f2i(q2.z), phz = (uint32_t)f2i(q2.w);
+            // the plane a ray meets first on an axis is the lower one when it
+            // travels up that axis and the upper one otherwise: pick the near and
+            // far plane words once per record (the sign of the inverse direction
+            // is the direction's, also for +-0), so that no per-child min/max of
+            // the two slab distances is needed
+            const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
+            const uint32_t lox = (uint32_t)f2i(q1.z), loy = (uint32_t)f2i(q1.w), loz = (uint32_t)f2i(q2.x);
+            const uint32_t hix = (uint32_t)f2i(q2.y), hiy = (uint32_t)f2i(q2.z), hiz = (uint32_t)f2i(q2.w);
+            const uint32_t plx = nx ? hix : lox, ply = ny ? hiy : loy, plz = nz ? hiz : loz;   // near
+            const uint32_t phx = nx ? lox : hix, phy = ny ? loy : hiy, phz = nz ? loz : hiz;   // far
             const f2 ox{r.ox, r.ox}, oy{r.oy, r.oy}, oz{r.oz, r.oz};
             const f2 ix{r.ix, r.ix}, iy{r.iy, r.iy}, iz{r.iz, r.iz};
             float key[4];
@@ -375,8 +383,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 const f2 by = __builtin_elementwise_fma(f2{RT_BYTE(ply, k), RT_BYTE(phy, k)}, fs_y, fo_y); \
                 const f2 bz = __builtin_elementwise_fma(f2{RT_BYTE(plz, k), RT_BYTE(phz, k)}, fs_z, fo_z); \
                 const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
-                const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y)); \
-                const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y)); \
+                const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
+                const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
                 const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;      \
                 key[k] = hit ? tn : kF32Inf;                                                \
                 n_hit += hit ? 1 : 0;                                                       \
