@@ -375,7 +375,6 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const f2 ix{r.ix, r.ix}, iy{r.iy, r.iy}, iz{r.iz, r.iz};
             float key[4];
             uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
-            int n_hit = 0;
 #define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
 #define RT_SLAB(k)                                                                          \
             {                                                                               \
@@ -387,7 +386,6 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
                 const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;      \
                 key[k] = hit ? tn : kF32Inf;                                                \
-                n_hit += hit ? 1 : 0;                                                       \
             }
             RT_SLAB(0)
             RT_SLAB(1)
@@ -396,13 +394,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 #undef RT_SLAB
 #undef RT_BYTE
             wide_sort4(key, ref);
-            if (n_hit == 0) {
+            // missed children carry +inf and sort last
+            if (!(key[0] < kF32Inf)) {
                 alive = pop_next();
             } else {
                 // farthest first, so that the nearest of the rest is popped first
-                if (n_hit > 3) push(ref[3], key[3]);
-                if (n_hit > 2) push(ref[2], key[2]);
-                if (n_hit > 1) push(ref[1], key[1]);
+                if (key[3] < kF32Inf) push(ref[3], key[3]);
+                if (key[2] < kF32Inf) push(ref[2], key[2]);
+                if (key[1] < kF32Inf) push(ref[1], key[1]);
                 stand_on(ref[0]);
             }
         }
