@@ -211,10 +211,10 @@ def main():
                                          stream=stream, want_stats=True)
 
     def run_step(step, collect):
-        rays, kernel_ms = 0, 0.0
+        rays, kernel_ms, launches = 0, 0.0, 0
         if queue is None:
             st = render_tiles(my_tiles, step)
-            rays, kernel_ms = st["rays"], st["kernel_ms"]
+            rays, kernel_ms, launches = st["rays"], st["kernel_ms"], st["kernel_launches"]
             if not args.no_gather:
                 if coll_dev == "cuda":
                     tiles.gather_static(d_tiles, tile_list, world, rank, frame)
@@ -232,6 +232,7 @@ def main():
                 st = render_tiles(group, step)
                 rays += st["rays"]
                 kernel_ms += st["kernel_ms"]
+                launches += st["kernel_launches"]
                 off = 0
                 for (tid, x, y, w, h) in group:
                     frame[y:y + h, x:x + w] = d_tiles[off:off + w * h * 4].view(h, w, 4)
@@ -241,6 +242,7 @@ def main():
         if collect:
             collect["rays"] += rays
             collect["kernel_ms"] += kernel_ms
+            collect["launches"] += launches
         return rays
 
     # ---- bytes/ray of this workload from the counting kernel on a sample tile (untimed)
@@ -267,7 +269,7 @@ def main():
 
     for w_ in range(args.warmup):
         run_step(-1 - w_, None)
-    acc = {"rays": 0, "kernel_ms": 0.0}
+    acc = {"rays": 0, "kernel_ms": 0.0, "launches": 0}
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -324,6 +326,8 @@ def main():
                          "nodes_per_ray": round(nodes_per_ray, 2),
                          "tris_per_ray": round(tris_per_ray, 2),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
+                         "kernel_launches_per_step": acc["launches"] // max(args.steps, 1),
+                         "kernel_avg_launch_ms": round(acc["kernel_ms"] / max(acc["launches"], 1), 4),
                          "scene_mb": round(scene_mb, 1),
                          "note": "achieved = rays x bytes_per_ray (this kernel's own counted record and "
                                  "triangle fetches) / traversal-launch time; achieved_reference_order prices "

@@ -216,6 +216,7 @@ typedef struct rt_stats {
     uint64_t tris_tested;
     double kernel_ms;               /* device time of the traversal kernels */
     double total_ms;                /* device time of the whole call */
+    uint64_t kernel_launches;       /* traversal launches kernel_ms is the sum of */
 } rt_stats;
 
 /* Host buffers in, host buffers out (copies through the device). */

@@ -39,7 +39,7 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("box_tests", C.c_uint64),
                 ("tris_fetched", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

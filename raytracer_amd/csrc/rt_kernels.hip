@@ -971,6 +971,7 @@ rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits,
         TRY_CLEAN(hipEventElapsedTime(&ms, e0, e1));
         stats->kernel_ms = ms;
         stats->total_ms = ms;
+        stats->kernel_launches = 1;
         stats->rays = n;
         if (want_counters) {
             unsigned long long c[5];
@@ -1166,6 +1167,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             (void)hipEventDestroy(pr.second);
         }
         stats->kernel_ms = kms;
+        stats->kernel_launches = trace_events.size();
         unsigned long long total = 0;
         HIP_TRY(hipMemcpy(&total, w.ray_total, 8, hipMemcpyDeviceToHost));
         stats->rays = total;
