@@ -163,11 +163,11 @@ rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *reco
     st = rt::flatten(*mesh, bvh->bvh, flat);
     if (st != RT_OK) return st;
     if (!flat.fast_ok) return fail(RT_ERR_INVALID, "tree does not fit the ordered-traversal encoding (more than 2^24-2 triangles or deeper than 60)");
-    *n_records = flat.pairs.size() / rtc::kWideFloats;
+    *n_records = flat.wide.size() / rtc::kWideFloats;
     *root_ref = flat.fast_root;
     if (records) {
         if (capacity_records < *n_records) return fail(RT_ERR_INVALID, "records buffer too small");
-        std::memcpy(records, flat.pairs.data(), flat.pairs.size() * 4);
+        std::memcpy(records, flat.wide.data(), flat.wide.size() * 4);
     }
     return RT_OK;
     RT_GUARD_END

@@ -226,25 +226,25 @@ struct WideBuilder {
     }
 };
 
-void build_pairs(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t> &skip, FlatScene &out) {
-    out.pairs.clear();
+void build_wide(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t> &skip, FlatScene &out) {
+    out.wide.clear();
     out.fast_ok = false;
     out.fast_root = 0;
     if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
-    WideBuilder b{mesh, bvh, skip, out.pairs, {}, 0};
+    WideBuilder b{mesh, bvh, skip, out.wide, {}, 0};
     b.bin.reserve((size_t)bvh.n_nodes * 2);
     const int32_t root = b.import_tree();
     const WideBuilder::BNode &rn = b.bin[(size_t)root];
     if (rn.left < 0) {
         if (rn.count <= 0) return;      // a tree whose root is an empty leaf has nothing to traverse in order
         out.fast_root = b.leaf_ref(rn); // the root is entered without a box test
-        out.pairs.resize(rtc::kWideFloats, 0.0f);
+        out.wide.resize(rtc::kWideFloats, 0.0f);
     } else {
         out.fast_root = b.emit(root, 1);
     }
     // every level can leave three entries on a lane's stack
     if (3 * b.max_wide_depth > rtc::kFastStackEntries) {
-        out.pairs.clear();
+        out.wide.clear();
         out.fast_root = 0;
         return;
     }
@@ -313,7 +313,7 @@ rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out) {
         out.tri_mat[(size_t)pos] = mat | (mesh.is_light[mat] ? rtc::kLightBit : 0);
         if (mesh.texcoords) std::memcpy(&out.tri_uv[6 * (size_t)pos], mesh.texcoords + 6 * (size_t)id, 24);
     }
-    build_pairs(mesh, bvh, skip, out);
+    build_wide(mesh, bvh, skip, out);
     return RT_OK;
 }
 

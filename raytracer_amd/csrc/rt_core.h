@@ -74,7 +74,7 @@ struct DevScene {
     //            | first triangle; unused slot -> kLeafBit (count 0)
     // A plane decodes as fma(offset, step, origin); decoded boxes contain the
     // binary tree's boxes (lower planes rounded down, upper planes up).
-    const f4 *pairs;
+    const f4 *wide;
     uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
     int32_t fast_ok;            // 0: tree does not fit the fast encoding
     const double *cam_tab;      // n_cam * 2
@@ -85,7 +85,6 @@ struct DevScene {
 constexpr int32_t kLightBit = 1 << 30;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefDone = 0xFFFFFFFFu;   // empty-stack marker (count 127, start 2^24-1 is never built)
-constexpr int32_t kFastMaxLeaf = 126;
 constexpr int32_t kFastSplitLeaf = 2;   // larger leaves are cut in two for the ordered traversal
 constexpr int32_t kWideFloats = 16;     // one ordered-traversal record: frame + 4 quantised child boxes + 4 refs = 64 bytes
 constexpr int32_t kFastStackEntries = 96;   // per-ray stack of the ordered traversal
@@ -243,7 +242,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
     uint32_t cur = s.fast_root;
     for (;;) {
         while ((cur & kLeafBit) == 0) {
-            const float *q = reinterpret_cast<const float *>(s.pairs) + (size_t)kWideFloats * (size_t)cur;
+            const float *q = reinterpret_cast<const float *>(s.wide) + (size_t)kWideFloats * (size_t)cur;
             if (COUNT) { c->nodes_visited++; c->box_tests += 4; }
             float key[4];
             uint32_t ref[4];

@@ -43,9 +43,9 @@ struct Scene {
     // flattened buffers (HBM)
     rtc::f4 *d_nodes = nullptr;
     rtc::f4 *d_tris = nullptr;
-    rtc::f4 *d_pairs = nullptr;        // ordered-traversal records (fast mode), may be null
+    rtc::f4 *d_wide = nullptr;        // ordered-traversal records (fast mode), may be null
     uint32_t fast_root = 0;
-    uint64_t pair_bytes = 0;
+    uint64_t wide_bytes = 0;
     int32_t *d_tri_mat = nullptr;
     float *d_kd = nullptr;
     float *d_tri_uv = nullptr;

@@ -38,7 +38,7 @@ struct FlatScene {
     std::vector<float> tris;       // n_tris * 12 floats (3 x 16-byte words)
     std::vector<int32_t> tri_mat;  // material id | light bit
     std::vector<float> tri_uv;     // n_tris * 6 or empty
-    std::vector<float> pairs;      // ordered-traversal records, 16 floats each (may be empty)
+    std::vector<float> wide;       // ordered-traversal records, 16 floats each (may be empty)
     uint32_t fast_root = 0;
     bool fast_ok = false;
 };

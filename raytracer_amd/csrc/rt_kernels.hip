@@ -351,7 +351,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (m_desc == 0) break;
             if ((int)__popcll(m_desc) < descend_min && __ballot(idx >= 0 && alive && tri_n > 0) != 0) break;
             if (!descending) continue;
-            const f4 *q = s.pairs + 4 * (size_t)cur;
+            const f4 *q = s.wide + 4 * (size_t)cur;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // frame of the record, then per child: decode the six planes with one
@@ -756,9 +756,9 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     sc->node_bytes = flat.nodes.size() * 4;
     sc->tri_bytes = flat.tris.size() * 4;
     if (flat.fast_ok) {
-        if ((st = upload(&sc->d_pairs, flat.pairs.data(), flat.pairs.size() * 4)) != RT_OK) return st;
+        if ((st = upload(&sc->d_wide, flat.wide.data(), flat.wide.size() * 4)) != RT_OK) return st;
         sc->fast_root = flat.fast_root;
-        sc->pair_bytes = flat.pairs.size() * 4;
+        sc->wide_bytes = flat.wide.size() * 4;
     }
     if ((st = upload(&sc->d_cursors, nullptr, kCursorSlots * sizeof(uint32_t))) != RT_OK) return st;
     HIP_TRY(hipMemset(sc->d_cursors, 0, kCursorSlots * sizeof(uint32_t)));
@@ -822,7 +822,7 @@ void scene_destroy(Scene *sc) {
     workspace_free(*sc);
     for (uint8_t *p : sc->tex_ptrs)
         if (p) (void)hipFree(p);
-    void *ptrs[] = {sc->d_pairs, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+    void *ptrs[] = {sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -845,9 +845,9 @@ static DevScene dev_view(const Scene &sc) {
     d.n_tris = sc.n_tris;
     d.n_cam = sc.n_cam;
     d.n_light = sc.n_light;
-    d.pairs = sc.d_pairs;
+    d.wide = sc.d_wide;
     d.fast_root = sc.fast_root;
-    d.fast_ok = sc.d_pairs ? 1 : 0;
+    d.fast_ok = sc.d_wide ? 1 : 0;
     return d;
 }
 
@@ -881,13 +881,13 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
     // wave scheduling thresholds (refill, descend_min, leaf_min): measured optimum per kernel
-    const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_pairs;
+    const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_wide;
     const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 60 : 48);
     const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 32 : 24);
     const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 16 : 8);
     switch (mode) {
     case RT_MODE_FAST_F32:
-        if (sc.d_pairs) {
+        if (sc.d_wide) {
             const int rb = t_refill;
             if (d_counters) {
                 hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);

@@ -52,10 +52,10 @@ void emul_trace(const float *nodes, int32_t n_nodes, const float *tris, int32_t 
     }
 }
 
-void emul_trace_fast(const float *pairs, uint32_t fast_root, const float *tris, int32_t n_tris,
+void emul_trace_fast(const float *wide, uint32_t fast_root, const float *tris, int32_t n_tris,
                      const EmulRay *rays, int64_t n, EmulHit *hits, uint64_t *counters) {
     DevScene s{};
-    s.pairs = reinterpret_cast<const f4 *>(pairs);
+    s.wide = reinterpret_cast<const f4 *>(wide);
     s.fast_root = fast_root;
     s.tris = reinterpret_cast<const f4 *>(tris);
     s.n_tris = n_tris;
