@@ -236,12 +236,15 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 }
 
 // ---------------------------------------------------------------------------
-// Traversal, fast mode: same box and triangle arithmetic, but the nearer child
-// is entered first and the farther one waits on a per-lane stack, so most of the
-// tree behind the first hit is never fetched.  The stack's top kStackLds entries
-// live in LDS ([entry][lane], 8 bytes each: child reference + entry distance),
-// deeper entries spill to scratch.  A popped entry whose entry distance is no
-// longer below the current hit distance is dropped without touching memory.
+// Traversal, fast mode, over the 4-wide view of the tree: a step decodes the four
+// child boxes of one 64-byte record, runs the reference's slab arithmetic on
+// them (the decoded boxes contain the reference's), enters the nearest child
+// that is hit and leaves the others on a per-lane stack, farthest first, so most
+// of the tree behind the first hit is never fetched.  The stack's top kStackLds
+// entries live in LDS ([entry][lane], 8 bytes each: child reference + entry
+// distance), deeper entries spill to scratch.  A popped entry whose entry
+// distance is no longer below the current hit distance is dropped without
+// touching memory.  Triangle arithmetic is the reference's.
 //
 // The loop alternates two phases, "descend through interior records until this
 // lane holds a leaf" and "test the leaf's triangles", so that the lanes of a
