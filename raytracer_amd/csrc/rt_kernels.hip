@@ -997,31 +997,48 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
     if (sc.ws_paths < paths || sc.ws_L < L || sc.ws_B < B) {
         workspace_free(sc);
         const size_t P = paths, qcap = P * (Lc + 1);
+        bool out_of_memory = false;
         auto alloc = [&](void **p, size_t bytes) -> hipError_t {
             hipError_t e = hipMalloc(p, bytes ? bytes : 16);
             if (e == hipSuccess) sc.ws_allocs.push_back(*p);
+            if (e == hipErrorOutOfMemory) {
+                out_of_memory = true;
+                (void)hipGetLastError();   // clear the sticky error so that a smaller retry can succeed
+            }
             return e;
         };
+        // an allocation that does not fit is reported as RT_ERR_NOMEM after the partial
+        // workspace is released, so that the caller can retry with a smaller batch
+#define WS_TRY(expr)                                                                      \
+        do {                                                                              \
+            hipError_t e__ = (expr);                                                      \
+            if (e__ != hipSuccess) {                                                      \
+                workspace_free(sc);                                                       \
+                return fail(out_of_memory ? RT_ERR_NOMEM : RT_ERR_DEVICE,                 \
+                            std::string(#expr) + ": " + hipGetErrorString(e__));          \
+            }                                                                             \
+        } while (0)
         PathBuffers &b = sc.ws;
         std::memset(&b, 0, sizeof b);
         for (int i = 0; i < 2; ++i) {
-            HIP_TRY(alloc(reinterpret_cast<void **>(&b.rays[i]), qcap * sizeof(rt_ray)));
-            HIP_TRY(alloc(reinterpret_cast<void **>(&b.hits[i]), qcap * sizeof(rt_hit)));
+            WS_TRY(alloc(reinterpret_cast<void **>(&b.rays[i]), qcap * sizeof(rt_ray)));
+            WS_TRY(alloc(reinterpret_cast<void **>(&b.hits[i]), qcap * sizeof(rt_hit)));
         }
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.counts), (size_t)(B + 3) * sizeof(uint32_t) + 256));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.state), P));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.cur_dir), P * 12));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.rng_stream), P * 8));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.shading_terms), P * (size_t)(B + 1) * 12));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.radiance), P * 12));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.ray_total), 64));
-        HIP_TRY(alloc(reinterpret_cast<void **>(&b.trav_counters), 64));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.counts), (size_t)(B + 3) * sizeof(uint32_t) + 256));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.state), P));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.cur_dir), P * 12));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_stream), P * 8));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.shading_terms), P * (size_t)(B + 1) * 12));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.radiance), P * 12));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.ray_total), 64));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.trav_counters), 64));
+#undef WS_TRY
         sc.ws_paths = paths;
         sc.ws_L = L;
         sc.ws_B = B;
@@ -1079,7 +1096,15 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     if (n_samp < 1) n_samp = 1;
     if (n_samp > (size_t)sample_count) n_samp = (size_t)(sample_count > 0 ? sample_count : 1);
     PathBuffers w;
-    st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
+    // the workspace is sized by the batch; when it does not fit in free device
+    // memory, halve the batch (down to 1M samples) and remember the smaller bound
+    for (;;) {
+        st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
+        if (st != RT_ERR_NOMEM || n_pix * n_samp <= ((size_t)1 << 20)) break;
+        if (n_samp > 1) n_samp = (n_samp + 1) / 2;
+        else n_pix = (n_pix + 1) / 2;
+        sc.max_paths_in_flight = n_pix * n_samp;
+    }
     if (st != RT_OK) return st;
     if (!tiles.empty()) {
         if (sc.tile_cap < tiles.size()) {

@@ -205,3 +205,41 @@ def test_textured_room_bit_exact(product_lib, oracle, gpu_device):
     plain.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
                             api.default_sample_table(100001, 0xC0FFEE02))
     assert not np.array_equal(plain.render_tile(oracle.pass_from_dict(d))["rgba"], ref["rgba"])
+
+
+def test_batch_shrinks_when_device_memory_is_short(cornell_pair):
+    """The path workspace is sized by the batch (about 370 bytes per camera
+    sample at 4 bounces).  With almost all device memory taken, a frame whose
+    default batch would not fit is rendered in smaller batches instead of
+    failing, and the image does not change."""
+    import torch
+    scene, _osc = cornell_pair
+    W, H = 2048, 1536                       # 3.1M samples per spp, about 1.2 GB of workspace
+    d = scenes.make_pass_dict(W, H, CORNELL_CAM, spp=2, bounces=4, light_samples=1,
+                              intensity=100.0, seed=3)
+    p = api.pass_from_dict(d)
+    accum = torch.empty((W * H * 3,), dtype=torch.float32, device="cuda")
+    rgba_a = torch.zeros((W * H * 4,), dtype=torch.uint8, device="cuda")
+    rgba_b = torch.zeros_like(rgba_a)
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.set_max_paths(1 << 23)
+    scene.render_tile_device(p, accum.data_ptr(), rgba_a.data_ptr(), stream=stream, want_stats=True)
+    torch.cuda.synchronize()
+    # a fresh scene handle (no workspace yet) with only ~0.9 GB of device memory left
+    sc = cornell()
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 16)
+    scene2 = api.Scene(mesh, bvh, torch.cuda.current_device())
+    scene2.set_max_paths(1 << 23)
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    hog = torch.empty((max(free - (900 << 20), 0),), dtype=torch.uint8, device="cuda")
+    try:
+        st = scene2.render_tile_device(p, accum.data_ptr(), rgba_b.data_ptr(), stream=stream,
+                                       want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert st["rays"] > W * H * 2
+    assert torch.equal(rgba_a, rgba_b)
