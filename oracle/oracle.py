@@ -192,7 +192,8 @@ class Scene:
                                          _ptr(self.is_light), m)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        # at interpreter shutdown module globals may already be gone
+        if getattr(self, "_h", None) and lib is not None:
             lib().orc_scene_destroy(self._h)
             self._h = None
 

@@ -147,7 +147,8 @@ class Bvh:
         return rec, root.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        # at interpreter shutdown module globals may already be gone
+        if getattr(self, "_h", None) and lib is not None:
             lib().rt_bvh_destroy(self._h)
             self._h = None
 
@@ -198,7 +199,8 @@ class Scene:
         self.device = device
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        # at interpreter shutdown module globals may already be gone
+        if getattr(self, "_h", None) and lib is not None:
             lib().rt_scene_destroy(self._h)
             self._h = None
 

@@ -77,7 +77,8 @@ class Backend:
         check(_lib().rtb_set_mode(self._h, mode))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        # at interpreter shutdown module globals may already be gone
+        if getattr(self, "_h", None) and _lib is not None:
             _lib().rtb_destroy(self._h)
             self._h = None
 
