@@ -183,7 +183,12 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             if (m_walk == 0) break;
             if ((int)__popcll(m_walk) < descend_min && __ballot(idx >= 0 && leaf_n > 0) != 0) break;
             if (!walking) continue;
-            const f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
+            f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
+            // keep the record two 16-byte loads: left alone the compiler splits it into
+            // four 8-byte ones around the root test below, and the kernel is bound by the
+            // number of per-lane loads
+            asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(lo.w));
+            asm volatile("" : "+v"(hi.x), "+v"(hi.y), "+v"(hi.z), "+v"(hi.w));
             const int32_t a = f2i(lo.w), b = f2i(hi.w);
             bool pass = true;
             if (node != 0) {
