@@ -299,7 +299,7 @@ def main():
         achieved = rank_rays * bpr / (acc["kernel_ms"] * 1e-3) / 1e9 if acc["kernel_ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.mode == "fast":   # the counters were collected on the ordered kernel
             with open(tpath) as f:
                 traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
         out = {
