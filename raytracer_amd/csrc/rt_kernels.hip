@@ -216,13 +216,23 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             if ((int)__popcll(m_leaf) < leaf_min &&
                 (int)__popcll(__ballot(idx >= 0 && node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
             if (!in_leaf) continue;
-            const f4 *q = s.tris + 3 * (size_t)leaf_a;
-            const f4 q0 = q[0], q1 = q[1], q2 = q[2];
-            if (COUNT) c_fetch++;
-            const bool tested = tri_test(r, q0, q1, q2, leaf_a, h);
+            // two triangles per step, fetched together so that their loads overlap,
+            // tested in array order
+            const bool two = leaf_n > 1;
+            const f4 *qa = s.tris + 3 * (size_t)leaf_a;
+            const f4 *qb = qa + (two ? 3 : 0);
+            const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
+            const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
+            if (COUNT) c_fetch += two ? 2 : 1;
+            bool tested = tri_test(r, a0, a1, a2, leaf_a, h);
             if (COUNT && tested) c_test++;
-            leaf_a++;
-            leaf_n--;
+            if (two) {
+                tested = tri_test(r, b0, b1, b2, leaf_a + 1, h);
+                if (COUNT && tested) c_test++;
+            }
+            leaf_a += 2;
+            leaf_n -= 2;
+            if (leaf_n < 0) leaf_n = 0;
         }
     }
     if (COUNT) {
