@@ -57,6 +57,14 @@ RT_HD float i2f(int i) {
 // ---------------------------------------------------------------------------
 struct DevScene {
     const f4 *nodes;
+    // The same reference-order tree with explicit links, free of the preorder
+    // layout (may be null): (min.xyz, bits next)(max.xyz, bits w).  Interior:
+    // next = where to go when the box fails, w = -1 - index of the left child.
+    // Leaf: next = where to go after the leaf, w = count << 24 | first triangle.
+    // The n_top nodes nearest the root come first in the array so that a block
+    // can keep them in LDS.
+    const f4 *linked;
+    int32_t n_top;
     const f4 *tris;
     const int32_t *tri_mat;     // material id, bit 30 set when the material is "Light"
     const float *kd;            // n_materials * 3

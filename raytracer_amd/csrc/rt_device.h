@@ -43,6 +43,8 @@ struct Scene {
     // flattened buffers (HBM)
     rtc::f4 *d_nodes = nullptr;
     rtc::f4 *d_tris = nullptr;
+    rtc::f4 *d_linked = nullptr;      // reference-order tree with explicit links, top levels first (may be null)
+    int32_t n_top = 0;
     rtc::f4 *d_wide = nullptr;        // ordered-traversal records (fast mode), may be null
     uint32_t fast_root = 0;
     uint64_t wide_bytes = 0;

@@ -128,11 +128,22 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 // Traversal, reference order.  One lane = one ray; the wave is persistent.
 // ---------------------------------------------------------------------------
 
-template <typename Real, bool COUNT>
+// TOP: the tree is read through its linked view (DevScene::linked), whose
+// first n_top nodes -- the levels nearest the root, a third of all node
+// fetches -- are copied into LDS by every block: the kernel is bound by the
+// number of per-lane global loads.  Visit order and arithmetic are the same.
+constexpr int kTopNodes = 512;
+
+template <typename Real, bool COUNT, bool TOP>
 __global__ void __launch_bounds__(256)
 k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
             unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
+    __shared__ f4 top[TOP ? 2 * kTopNodes : 1];
+    if (TOP) {
+        for (int i = threadIdx.x; i < 2 * s.n_top; i += blockDim.x) top[i] = s.linked[i];
+        __syncthreads();
+    }
     const uint32_t n = n_dev ? *n_dev : n_host;
     int32_t idx = -1;            // ray owned by this lane, -1 = idle
     RayFeed feed;
@@ -183,7 +194,19 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             if (m_walk == 0) break;
             if ((int)__popcll(m_walk) < descend_min && __ballot(idx >= 0 && leaf_n > 0) != 0) break;
             if (!walking) continue;
-            f4 lo = s.nodes[2 * node], hi = s.nodes[2 * node + 1];
+            f4 lo, hi;
+            if (TOP) {
+                if (node < s.n_top) {
+                    lo = top[2 * node];
+                    hi = top[2 * node + 1];
+                } else {
+                    lo = s.linked[2 * node];
+                    hi = s.linked[2 * node + 1];
+                }
+            } else {
+                lo = s.nodes[2 * node];
+                hi = s.nodes[2 * node + 1];
+            }
             // keep the record two 16-byte loads: left alone the compiler splits it into
             // four 8-byte ones around the root test below, and the kernel is bound by the
             // number of per-lane loads
@@ -196,7 +219,19 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
                 if (COUNT) c_box++;
                 pass = slab(r, lo, hi, t0, t1) && t0 < h.t && t1 > 0;
             }
-            if (b >= 0) {
+            if (TOP) {
+                // a = next node when this one fails or is a leaf; b = leaf range or ~left child
+                if (b >= 0) {
+                    if (pass) {
+                        leaf_a = b & 0xFFFFFF;
+                        leaf_n = b >> 24;
+                    }
+                    node = a;
+                } else {
+                    if (COUNT && pass) c_nodes++;
+                    node = pass ? -1 - b : a;
+                }
+            } else if (b >= 0) {
                 if (pass) {
                     leaf_a = a;
                     leaf_n = b;
@@ -734,6 +769,51 @@ struct DeviceGuard {
 
 }  // namespace
 
+// Linked form of the reference-order node array (DevScene::linked): the nodes
+// of the first levels (as many whole levels as fit max_top nodes) are moved to
+// the front, the others keep their preorder behind them, and the implicit
+// "next node = this one + 1" of the preorder array becomes an explicit link.
+// Returns false when a leaf does not fit the packed encoding (more than 127
+// triangles, or a first triangle beyond 2^24): such trees use the plain array.
+static bool link_nodes(const Bvh &bvh, const std::vector<float> &nodes, int32_t max_top,
+                       std::vector<float> &out, int32_t &n_top) {
+    const int32_t nn = bvh.n_nodes;
+    if (nn <= 0 || (int64_t)nn >= (1 << 30)) return false;
+    std::vector<int32_t> per_depth;
+    for (int32_t i = 0; i < nn; ++i) {
+        const int32_t d = bvh.depth[(size_t)i];
+        if (d < 0) return false;
+        if ((size_t)d >= per_depth.size()) per_depth.resize((size_t)d + 1, 0);
+        per_depth[(size_t)d]++;
+    }
+    int32_t top_depth = 0, count = 0;      // nodes with depth < top_depth go to the front
+    while ((size_t)top_depth < per_depth.size() && count + per_depth[(size_t)top_depth] <= max_top)
+        count += per_depth[(size_t)top_depth++];
+    n_top = count;
+    std::vector<int32_t> to_new((size_t)nn + 1);
+    int32_t next_top = 0, next_deep = n_top;
+    for (int32_t i = 0; i < nn; ++i)
+        to_new[(size_t)i] = bvh.depth[(size_t)i] < top_depth ? next_top++ : next_deep++;
+    to_new[(size_t)nn] = nn;               // "past the last node" stays the end marker
+    out.assign((size_t)nn * 8, 0.0f);
+    for (int32_t i = 0; i < nn; ++i) {
+        const float *src = &nodes[(size_t)i * 8];
+        float *dst = &out[(size_t)to_new[(size_t)i] * 8];
+        std::memcpy(dst, src, 32);
+        const int32_t a = rtc::f2i(src[3]), b = rtc::f2i(src[7]);
+        if (b >= 0) {                      // leaf: (first, count) -> next link + packed range
+            if (b > 127 || a < 0 || a >= (1 << 24)) return false;
+            dst[3] = rtc::i2f(to_new[(size_t)i + 1]);
+            dst[7] = rtc::i2f((b << 24) | a);
+        } else {                           // interior: skip link + left child
+            if (a < 0 || a > nn) return false;
+            dst[3] = rtc::i2f(to_new[(size_t)a]);
+            dst[7] = rtc::i2f(-1 - to_new[(size_t)i + 1]);
+        }
+    }
+    return true;
+}
+
 rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **out) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -762,6 +842,14 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     find_light(mesh, bvh.order, sc->light);
 
     if ((st = upload(&sc->d_nodes, flat.nodes.data(), flat.nodes.size() * 4)) != RT_OK) return st;
+    {
+        std::vector<float> linked;
+        int32_t n_top = 0;
+        if (link_nodes(bvh, flat.nodes, kTopNodes, linked, n_top)) {
+            if ((st = upload(&sc->d_linked, linked.data(), linked.size() * 4)) != RT_OK) return st;
+            sc->n_top = n_top;
+        }
+    }
     if ((st = upload(&sc->d_tris, flat.tris.data(), flat.tris.size() * 4)) != RT_OK) return st;
     if ((st = upload(&sc->d_tri_mat, flat.tri_mat.data(), flat.tri_mat.size() * 4)) != RT_OK) return st;
     if ((st = upload(&sc->d_kd, mesh.kd, (size_t)mesh.n_materials * 12)) != RT_OK) return st;
@@ -840,7 +928,7 @@ void scene_destroy(Scene *sc) {
     workspace_free(*sc);
     for (uint8_t *p : sc->tex_ptrs)
         if (p) (void)hipFree(p);
-    void *ptrs[] = {sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+    void *ptrs[] = {sc->d_linked, sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -850,6 +938,8 @@ void scene_destroy(Scene *sc) {
 static DevScene dev_view(const Scene &sc) {
     DevScene d{};
     d.nodes = sc.d_nodes;
+    d.linked = sc.d_linked;
+    d.n_top = sc.n_top;
     d.tris = sc.d_tris;
     d.tri_mat = sc.d_tri_mat;
     d.kd = sc.d_kd;
@@ -923,15 +1013,15 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         [[fallthrough]];
     case RT_MODE_STRICT_F32:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<float, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
+            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
-            hipLaunchKernelGGL((k_trace_ref<float, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
+            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         break;
     case RT_MODE_FP64:
         if (d_counters)
-            hipLaunchKernelGGL((k_trace_ref<double, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
+            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
-            hipLaunchKernelGGL((k_trace_ref<double, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf);
+            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         break;
     default:
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
