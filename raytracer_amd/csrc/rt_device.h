@@ -22,11 +22,11 @@ struct PathBuffers {
     uint32_t *counts;          // queue lengths: [0] primaries, [k+1] rays emitted at vertex k
     uint8_t *state;
     uint8_t *n_terms;
-    float *cur_dir;            // P*3
     uint32_t *rng_ctr;
     uint64_t *rng_stream;      // per path: counter-RNG stream key
     int32_t *bounce_q;
     int32_t *shadow_q;         // P*L
+    float *shadow_dist;        // P*L: length of the shadow ray in that slot
     float *shadow_col;         // P*L*3
     float *shading_terms;      // (B+1)*P*3, vertex-major
     float *brdf_terms;         // (B+1)*P*3

@@ -540,9 +540,6 @@ k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
     w.n_terms[id] = 0;
     w.rng_ctr[id] = 0;
     w.rng_stream[id] = rng_stream(ctx.rng_seed, ctx.path_index);
-    w.cur_dir[3 * (size_t)id + 0] = d.x;
-    w.cur_dir[3 * (size_t)id + 1] = d.y;
-    w.cur_dir[3 * (size_t)id + 2] = d.z;
 }
 
 // Sum of the shadow samples that reached the light, scaled and clamped
@@ -555,7 +552,7 @@ __device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &
         const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
         const int32_t q = w.shadow_q[slot];
         if (q < 0) continue;
-        const float dist = w.rays[in][q].tmax;
+        const float dist = w.shadow_dist[slot];   // the shadow ray's tmax, kept here to spare a gather
         const rt_hit sh = w.hits[in][q];
         const bool reached = sh.t < kF32Max;   // rayCast returned a result
         const bool lit = reached && (sh.t >= dist ||
@@ -637,6 +634,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
                 rp[0] = f4{point.x, point.y, point.z, dist};
                 rp[1] = f4{dn.x, dn.y, dn.z, 0.0f};
                 w.shadow_q[slot] = (int32_t)q;
+                w.shadow_dist[slot] = dist;
                 store3(w.shadow_col, slot, col);
             } else {
                 w.shadow_q[slot] = -1;
@@ -665,11 +663,10 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         rp[0] = f4{point.x, point.y, point.z, kF32Max};
         rp[1] = f4{sample.x, sample.y, sample.z, 0.0f};
         w.bounce_q[id] = (int32_t)bq;
-        const v3 cur{w.cur_dir[3 * (size_t)id], w.cur_dir[3 * (size_t)id + 1], w.cur_dir[3 * (size_t)id + 2]};
-        const float f = brdf_factor(cur, sample, normal);
+        // the direction the path arrived with is the traced ray's own (trace.go:95 currentRay)
+        const float f = brdf_factor(rd, sample, normal);
         // provisional: zeroed by the next vertex if the bounce ray hits nothing
         store3(w.brdf_terms, (size_t)k * P + id, v3{diffuse.x * f, diffuse.y * f, diffuse.z * f});
-        store3(w.cur_dir, id, sample);
     }
 }
 
@@ -1132,11 +1129,11 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
         WS_TRY(alloc(reinterpret_cast<void **>(&b.counts), (size_t)(B + 3) * sizeof(uint32_t) + 256));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.state), P));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.cur_dir), P * 12));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_stream), P * 8));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
+        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_dist), P * Lc * 4));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.shading_terms), P * (size_t)(B + 1) * 12));
         WS_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
