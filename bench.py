@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=8, help="tiles taken per pull with --dynamic")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
     ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
+    ap.add_argument("--pretend-world", type=int, default=0,
+                    help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
+                         "no collectives (estimates the per-rank time of a larger job)")
     return ap.parse_args()
 
 
@@ -153,6 +156,7 @@ def main():
             dist.init_process_group("gloo")
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
+    pretend = args.pretend_world if world == 1 else 0
     wl = WORKLOADS[args.workload]
     mode = {"strict": api.MODE_STRICT_F32, "fast": api.MODE_FAST_F32, "fp64": api.MODE_FP64}[args.mode]
 
@@ -170,10 +174,10 @@ def main():
     tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
 
     tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
-    my_tiles = [tile_list[i] for i in tiles.static_assignment(len(tile_list), world, rank)]
+    my_tiles = [tile_list[i] for i in tiles.static_assignment(len(tile_list), pretend or world, rank)]
     # every rank's tile images live back to back in one buffer; ranks own equal
     # numbers of pixels only when the tile grid divides evenly, so pad to the maximum
-    px_of = [sum(t[3] * t[4] for t in tile_list[r::world]) for r in range(world)]
+    px_of = [sum(t[3] * t[4] for t in tile_list[r::(pretend or world)]) for r in range(world)]
     my_px, max_px = px_of[rank], max(px_of)
     if args.dynamic:
         my_px = max_px = sum(t[3] * t[4] for t in tile_list)   # a rank may end up with any tile
@@ -215,7 +219,7 @@ def main():
         if queue is None:
             st = render_tiles(my_tiles, step)
             rays, kernel_ms, launches = st["rays"], st["kernel_ms"], st["kernel_launches"]
-            if not args.no_gather:
+            if not args.no_gather and not pretend:
                 if coll_dev == "cuda":
                     tiles.gather_static(d_tiles, tile_list, world, rank, frame)
                 else:
