@@ -283,3 +283,33 @@ def test_fast_mode_at_extreme_scales(product_lib, oracle, gpu_device, emul, scal
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
     # the scale must not make the scene invisible to the test
     assert (ref["tri"] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("n,use_bvh,leaf,depth", [(300, False, 6, 16), (4000, True, 200, 4), (4000, True, 1, 40),
+                                                  (2, True, 1, 4), (5000, True, 127, 3), (5000, True, 128, 3)])
+def test_reference_order_views(product_lib, oracle, gpu_device, n, use_bvh, leaf, depth):
+    """The reference-order kernel reads a linked copy of the node array whose
+    top levels sit in LDS; trees with a leaf of more than 127 triangles do not
+    fit that copy and are read from the plain preorder array.  Both must give
+    the oracle's hits and counters bit for bit: one big leaf, depth-capped
+    trees with large leaves on either side of the limit, single-triangle
+    leaves, a two-triangle scene."""
+    sc = scenes.soup(n, seed=900 + n + leaf, extent=0.6, size=0.1)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, use_bvh, leaf, depth)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    rays = random_rays(20000, seed=n + depth, extent=1.0)
+    rays["tmax"][::5] = np.float32(0.8)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax, counters=True)
+    for mode in (api.MODE_STRICT_F32, api.MODE_FP64):
+        hits, st = scene.trace_rays(rays, mode=mode, counters=True)
+        if mode == api.MODE_STRICT_F32:
+            _check(hits, ref)
+            c = ref["counters"]
+            assert (st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]) == \
+                (c["nodes_visited"], c["box_tests"], c["tris_fetched"], c["tris_tested"])
+        else:
+            assert (hits["tri_pos"] != ref["tri"]).mean() < 0.01
+    assert (ref["tri"] >= 0).sum() > 0
