@@ -183,7 +183,9 @@ rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
  * persistent blocks per CU, and the number of still-descending lanes below
  * which a wave of the ordered kernel turns to the lanes that wait on a leaf,
  * and the number of lanes inside a leaf below which it turns back (both
- * 1..64).  Results do not depend on them. */
+ * 1..64).  0 for any of the three lane counts selects the kernel's own default
+ * (they differ between the ordered and the reference-order kernel).  Results
+ * do not depend on them. */
 rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
                               int32_t blocks_per_cu, int32_t descend_min, int32_t leaf_min);
 /* When enabled, render calls that return rt_stats run the counting variant of

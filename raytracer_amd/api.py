@@ -227,7 +227,8 @@ class Scene:
     def set_max_paths(self, n):
         check(lib().rt_scene_set_max_paths(self._h, n))
 
-    def set_tuning(self, stack_entries=8, refill_below=60, blocks_per_cu=8, descend_min=32, leaf_min=16):
+    def set_tuning(self, stack_entries=8, refill_below=0, blocks_per_cu=8, descend_min=0, leaf_min=0):
+        """0 for a lane count = the kernel's own default."""
         check(lib().rt_scene_set_tuning(self._h, stack_entries, refill_below, blocks_per_cu, descend_min,
                                         leaf_min))
 

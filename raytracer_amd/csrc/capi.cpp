@@ -208,8 +208,8 @@ rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t re
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (stack_entries != 8 && stack_entries != 12 && stack_entries != 16 && stack_entries != 24)
         return fail(RT_ERR_INVALID, "stack_entries must be 8, 12, 16 or 24");
-    if (refill_below < 1 || refill_below > 64 || blocks_per_cu < 1 || blocks_per_cu > 64 ||
-        descend_min < 1 || descend_min > 64 || leaf_min < 1 || leaf_min > 64)
+    if (refill_below < 0 || refill_below > 64 || blocks_per_cu < 1 || blocks_per_cu > 64 ||
+        descend_min < 0 || descend_min > 64 || leaf_min < 0 || leaf_min > 64)
         return fail(RT_ERR_INVALID, "tuning value out of range");
     scene->impl->tune_stack = stack_entries;
     scene->impl->tune_refill = refill_below;
