@@ -312,16 +312,24 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
              unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
     constexpr int kStackSpill = kStackTotal - kStackLds;
     __shared__ uint2 lds_stack[4 * kStackLds * 64];
+    // Values that no descent step reads -- the hit's u and v, the ray's index and
+    // its direction (the descent uses the inverse direction) -- live in LDS,
+    // [value][thread]: the descent step is what sets the register count, and
+    // with it how many waves a SIMD holds.
+    __shared__ float park[6 * 256];
+    float *my_park = park + threadIdx.x;
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t lane = lane_id();
     uint2 *my_stack = lds_stack + (threadIdx.x >> 6) * (kStackLds * 64) + lane;
     uint2 spill[kStackSpill];
-    int32_t idx = -1;
+    bool busy = false;           // this lane holds a ray
     RayFeed feed;
-    Ray<float> r;
-    Hit<float> h;
-    uint32_t cur = 0;            // interior record when tri_n == 0
-    int32_t tri_i = 0, tri_n = 0;   // next triangle and how many remain in the current leaf
+    float r_ox = 0, r_oy = 0, r_oz = 0, r_ix = 0, r_iy = 0, r_iz = 0;   // origin and inverse direction
+    float h_t = 0;               // closest hit so far
+    int32_t h_pos = -1;
+    // where the lane stands, in the form of a child reference: an interior record
+    // index, or leaf bit | triangles left << 24 | next triangle
+    uint32_t where = 0;
     int32_t sp = 0;
     bool alive = false;          // this lane's ray still has work
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
@@ -334,15 +342,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     };
     // Stands the lane on `ref`: an interior record, or a leaf (never empty: empty
     // leaves carry NaN boxes that no ray enters).
-    auto stand_on = [&](uint32_t ref) {
-        if ((ref & kLeafBit) == 0) {
-            cur = ref;
-            tri_n = 0;
-        } else {
-            tri_i = (int32_t)(ref & 0xFFFFFFu);
-            tri_n = (int32_t)((ref >> 24) & 0x7Fu);
-        }
-    };
+    auto stand_on = [&](uint32_t ref) { where = ref; };
     // Next stacked entry that can still hold a closer hit; false when the ray is
     // finished.  The LDS slot is read unconditionally (index clamped) and replaced
     // from the spill array only when the entry lives there, so that both accesses
@@ -353,7 +353,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
             asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
             if (sp >= kStackLds) e = spill[sp - kStackLds];
-            if (i2f((int32_t)e.y) < h.t) {
+            if (i2f((int32_t)e.y) < h_t) {
                 stand_on(e.x);
                 return true;
             }
@@ -363,32 +363,38 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 
     for (;;) {
         // retire finished rays, refill idle lanes
-        if (idx >= 0 && !alive) {
+        if (busy && !alive) {
             f4 out;
-            out.x = i2f(h.pos);
-            out.y = h.t;
-            out.z = h.u;
-            out.w = h.v;
+            out.x = i2f(h_pos);
+            out.y = h_t;
+            out.z = my_park[0 * 256];
+            out.w = my_park[1 * 256];
+            const int32_t idx = f2i(my_park[2 * 256]);
             *reinterpret_cast<f4 *>(hits + idx) = out;
-            idx = -1;
+            busy = false;
         }
-        uint64_t active = __ballot(idx >= 0);
+        uint64_t active = __ballot(busy);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
             const int32_t mine = feed_take(feed, next, n, ~active);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
-                ray_init(r, a.x, a.y, a.z, b.x, b.y, b.z);
-                h.t = a.w;
-                h.u = 0;
-                h.v = 0;
-                h.pos = -1;
+                r_ox = a.x; r_oy = a.y; r_oz = a.z;
+                r_ix = 1.0f / b.x; r_iy = 1.0f / b.y; r_iz = 1.0f / b.z;   // ray.go:33-37
+                h_t = a.w;
+                h_pos = -1;
+                my_park[0 * 256] = 0.0f;
+                my_park[1 * 256] = 0.0f;
+                my_park[2 * 256] = i2f(mine);
+                my_park[3 * 256] = b.x;
+                my_park[4 * 256] = b.y;
+                my_park[5 * 256] = b.z;
                 sp = 0;
-                idx = mine;
+                busy = true;
                 alive = true;
                 stand_on(s.fast_root);
             }
-            active = __ballot(idx >= 0);
+            active = __ballot(busy);
         }
         if (active == 0) {
             if (feed.exhausted && feed.pos >= feed.end) break;
@@ -399,12 +405,12 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         // once fewer than descend_min lanes still descend while others wait on a
         // leaf: one long descent must not idle the wave.
         for (;;) {
-            const bool descending = idx >= 0 && alive && tri_n == 0;
+            const bool descending = busy && alive && (where & kLeafBit) == 0;
             const uint64_t m_desc = __ballot(descending);
             if (m_desc == 0) break;
-            if ((int)__popcll(m_desc) < descend_min && __ballot(idx >= 0 && alive && tri_n > 0) != 0) break;
+            if ((int)__popcll(m_desc) < descend_min && __ballot(busy && alive && (where & kLeafBit) != 0) != 0) break;
             if (!descending) continue;
-            const f4 *q = s.wide + 4 * (size_t)cur;
+            const f4 *q = s.wide + 4 * (size_t)where;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // frame of the record, then per child: decode the six planes with one
@@ -419,13 +425,13 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // far plane words once per record (the sign of the inverse direction
             // is the direction's, also for +-0), so that no per-child min/max of
             // the two slab distances is needed
-            const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
+            const bool nx = r_ix < 0, ny = r_iy < 0, nz = r_iz < 0;
             const uint32_t lox = (uint32_t)f2i(q1.z), loy = (uint32_t)f2i(q1.w), loz = (uint32_t)f2i(q2.x);
             const uint32_t hix = (uint32_t)f2i(q2.y), hiy = (uint32_t)f2i(q2.z), hiz = (uint32_t)f2i(q2.w);
             const uint32_t plx = nx ? hix : lox, ply = ny ? hiy : loy, plz = nz ? hiz : loz;   // near
             const uint32_t phx = nx ? lox : hix, phy = ny ? loy : hiy, phz = nz ? loz : hiz;   // far
-            const f2 ox{r.ox, r.ox}, oy{r.oy, r.oy}, oz{r.oz, r.oz};
-            const f2 ix{r.ix, r.ix}, iy{r.iy, r.iy}, iz{r.iz, r.iz};
+            const f2 ox{r_ox, r_ox}, oy{r_oy, r_oy}, oz{r_oz, r_oz};
+            const f2 ix{r_ix, r_ix}, iy{r_iy, r_iy}, iz{r_iz, r_iz};
             float key[4];
             uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
 #define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
@@ -437,7 +443,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;      \
+                const bool hit = tn <= tf && tn < h_t && tf > 0 && ref[k] != kLeafBit;      \
                 key[k] = hit ? tn : kF32Inf;                                                \
             }
             RT_SLAB(0)
@@ -464,29 +470,41 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         // holds a leaf, or when fewer than leaf_min do while enough lanes wait to
         // descend (the few keep their place in the leaf for the next round).
         for (;;) {
-            const bool in_leaf = idx >= 0 && alive && tri_n > 0;
+            const bool in_leaf = busy && alive && (where & kLeafBit) != 0;
             const uint64_t m_leaf = __ballot(in_leaf);
             if (m_leaf == 0) break;
             if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(__ballot(idx >= 0 && alive && tri_n == 0)) >= descend_min) break;
+                (int)__popcll(__ballot(busy && alive && (where & kLeafBit) == 0)) >= descend_min) break;
             if (!in_leaf) continue;
+            const int32_t tri_i = (int32_t)(where & 0xFFFFFFu), tri_n = (int32_t)((where >> 24) & 0x7Fu);
             const bool two = tri_n > 1;
             const f4 *qa = s.tris + 3 * (size_t)tri_i;
             const f4 *qb = qa + (two ? 3 : 0);
             const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
             const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
             if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
+            // the full ray and hit only exist here
+            Ray<float> r;
+            r.ox = r_ox; r.oy = r_oy; r.oz = r_oz;
+            r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
+            r.ix = r_ix; r.iy = r_iy; r.iz = r_iz;
+            Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
             bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
             if (COUNT && tested) c_test++;
             if (two) {
                 tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
                 if (COUNT && tested) c_test++;
             }
-            tri_i += 2;
-            tri_n -= 2;
-            if (tri_n <= 0) {
-                tri_n = 0;
+            if (h.pos != h_pos) {      // a triangle is accepted at most once
+                my_park[0 * 256] = h.u;
+                my_park[1 * 256] = h.v;
+                h_pos = h.pos;
+            }
+            h_t = h.t;
+            if (tri_n <= 2) {
                 alive = pop_next();
+            } else {
+                where = kLeafBit | ((uint32_t)(tri_n - 2) << 24) | (uint32_t)(tri_i + 2);
             }
         }
     }
