@@ -593,7 +593,7 @@ __device__ __forceinline__ void store3(float *base, size_t i, const v3 &v) {
 }
 
 // Path vertex k.  Reads queue (k & 1), writes queue ((k+1) & 1).
-__global__ void __launch_bounds__(kShadeBlock)
+__global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = id < b.P && w.state[id] == kActive;
