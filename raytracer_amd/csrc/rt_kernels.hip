@@ -338,10 +338,10 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
         if (sp < kStackLds) my_stack[sp * 64] = e;
         else if (sp < kStackTotal) spill[sp - kStackLds] = e;
-        sp++;   // deeper than both levels cannot happen: trees deeper than 60 use the other kernel
+        sp++;   // deeper than both levels cannot happen: a wide tree whose depth x 3 exceeds the stack is not built
     };
-    // Stands the lane on `ref`: an interior record, or a leaf (never empty: empty
-    // leaves carry NaN boxes that no ray enters).
+    // Stands the lane on `ref`: an interior record, or a leaf (never empty: unused
+    // slots are never hit and empty leaves are not stored).
     auto stand_on = [&](uint32_t ref) { where = ref; };
     // Next stacked entry that can still hold a closer hit; false when the ray is
     // finished.  The LDS slot is read unconditionally (index clamped) and replaced
