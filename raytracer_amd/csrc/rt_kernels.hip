@@ -1167,6 +1167,19 @@ static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuf
     return RT_OK;
 }
 
+// Timing events of one call, destroyed on every way out of it.
+struct EventPool {
+    std::vector<hipEvent_t> all;
+    ~EventPool() {
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+    hipError_t make(hipEvent_t *e) {
+        const hipError_t r = hipEventCreate(e);
+        if (r == hipSuccess) all.push_back(*e);
+        return r;
+    }
+};
+
 // True when two passes differ only in what may differ between tiles of one frame.
 static bool same_frame(const rt_pass &a, const rt_pass &b) {
     return std::memcmp(&a.camera, &b.camera, sizeof a.camera) == 0 &&
@@ -1244,18 +1257,19 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
     HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
     HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 8 * sizeof(unsigned long long), stream));
+    EventPool events;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     if (stats) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(events.make(&e0));
+        HIP_TRY(events.make(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
     auto timed_trace = [&](const rt_ray *rays, size_t cap, const uint32_t *cnt, rt_hit *hits) -> rt_status {
         hipEvent_t a = nullptr, b = nullptr;
         if (stats) {
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&b));
+            HIP_TRY(events.make(&a));
+            HIP_TRY(events.make(&b));
             trace_events.emplace_back(a, b);
             HIP_TRY(hipEventRecord(a, stream));
         }
@@ -1311,8 +1325,6 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
             kms += t;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
         }
         stats->kernel_ms = kms;
         stats->kernel_launches = trace_events.size();
@@ -1330,8 +1342,6 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             stats->tris_fetched = c[3];
             stats->tris_tested = c[4];
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     return RT_OK;
 }
