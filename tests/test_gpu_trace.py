@@ -313,3 +313,25 @@ def test_reference_order_views(product_lib, oracle, gpu_device, n, use_bvh, leaf
         else:
             assert (hits["tri_pos"] != ref["tri"]).mean() < 0.01
     assert (ref["tri"] >= 0).sum() > 0
+
+
+def test_tuning_does_not_change_results(soup20k):
+    """Stack size, refill threshold, grid size and the two phase thresholds only
+    steer scheduling: hits and counters stay identical in both kernels."""
+    _, _, _bvh, scene, _osc = soup20k
+    rays = random_rays(120000, seed=21)
+    rays["tmax"][::3] = np.float32(1.1)
+    try:
+        base = {}
+        for mode in (api.MODE_STRICT_F32, api.MODE_FAST_F32):
+            scene.set_tuning(8, 0, 8, 0, 0)
+            base[mode] = scene.trace_rays(rays, mode=mode, counters=True)
+        for tune in [(16, 64, 1, 64, 64), (24, 1, 3, 1, 1), (12, 33, 16, 17, 5), (8, 60, 8, 32, 16)]:
+            scene.set_tuning(*tune)
+            for mode in (api.MODE_STRICT_F32, api.MODE_FAST_F32):
+                hits, st = scene.trace_rays(rays, mode=mode, counters=True)
+                assert np.array_equal(hits.view(np.uint32), base[mode][0].view(np.uint32)), (tune, mode)
+                for key in ("nodes_visited", "box_tests", "tris_fetched", "tris_tested"):
+                    assert st[key] == base[mode][1][key], (tune, mode, key)
+    finally:
+        scene.set_tuning(8, 0, 8, 0, 0)
