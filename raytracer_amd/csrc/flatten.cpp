@@ -30,7 +30,7 @@ namespace {
 // the largest surface area is replaced by its own two children (in place, so
 // the reference's left-to-right order of the children is kept) until there are
 // four or only leaves are left.  The boxes are stored as 8-bit offsets from
-// the record's own frame (origin = lower corner of the union, one power-of-two
+// the record's own frame (origin = lower corner of the union, one
 // step per axis); lower planes are rounded down and upper planes up, and each
 // is checked with the very fused multiply-add the traversal decodes it with,
 // so a decoded box always CONTAINS the binary tree's box: the wide test passes
@@ -161,7 +161,7 @@ struct WideBuilder {
             }
             n = m;
         }
-        // frame: lower corner of the union and a power-of-two step per axis
+        // frame: lower corner of the union and a step per axis
         float origin[3], step[3];
         uint8_t qlo[4][3], qhi[4][3];
         for (int a = 0; a < 3; ++a) {
@@ -173,14 +173,12 @@ struct WideBuilder {
             }
             if (n == 0) { lo = 0; hi = 0; }
             origin[a] = lo;
-            int e;
             const float ext = hi - lo;
-            // smallest power of two s with 255 * s >= ext (rounded up generously), at least a denormal-safe floor
-            (void)std::frexp(ext > 0 ? ext / 255.0f : 0.0f, &e);
-            if (!(ext > 0)) e = -120;
-            if (e < -120) e = -120;
-            for (;; ++e) {
-                const float s = std::ldexp(1.0f, e);
+            // smallest step s with 255 * s >= ext that the check below accepts (any float, not only a
+            // power of two: the decode is one fma either way); a floor keeps empty extents finite
+            float s = ext > 0 ? ext / 255.0f : 0.0f;
+            if (!(s > 7.5e-37f)) s = 7.5e-37f;
+            for (;; s *= 1.000001f) {
                 bool ok = true;
                 for (int i = 0; i < n && ok; ++i) {
                     const BNode &c = bin[(size_t)kids[i]];
@@ -201,7 +199,7 @@ struct WideBuilder {
                     if (std::fmaf((float)q, s, lo) < c.mx[a]) ok = false;
                     qhi[i][a] = (uint8_t)q;
                 }
-                if (ok) { step[a] = s; break; }
+                if (ok || !std::isfinite(s)) { step[a] = s; break; }
             }
         }
         float *p = &recs[(size_t)rec * rtc::kWideFloats];

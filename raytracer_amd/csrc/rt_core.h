@@ -75,7 +75,7 @@ struct DevScene {
     // Ordered-traversal view of the same tree (fast mode): 4-wide records of 64
     // bytes (16 dwords):
     //   [0..2]  origin of the record's frame (lower corner of the children's union)
-    //   [3..5]  step per axis (a power of two)
+    //   [3..5]  step per axis (extent / 255, nudged up until every plane decodes outward)
     //   [6..8]  lower planes x, y, z: child c's 8-bit offset in byte c
     //   [9..11] upper planes x, y, z, likewise
     //   [12..15] child refs: interior -> record index; leaf -> kLeafBit | count << 24
