@@ -12,9 +12,13 @@
  * thread's last failure.  Nothing aborts across this boundary (the reference
  * maps failures to exitCode -1 + message, main.go:308-325).
  *
- * Threading: an rt_bvh / rt_scene is immutable after creation and may be
- * shared by threads; render/trace calls on one scene serialise on the HIP
- * stream they are given.  One scene lives on one GPU; multi-GPU callers
+ * Threading: an rt_bvh is immutable after creation and may be shared by
+ * threads.  An rt_scene may be shared too: its geometry is immutable, the
+ * rt_trace_rays* calls are independent of each other, and the render calls,
+ * which share the scene's path workspace, take turns (a lock on the host; on
+ * the GPU each waits for the previous one, whatever streams they were given).
+ * The rt_scene_set_* calls must not run while another thread uses the scene.
+ * One scene lives on one GPU; multi-GPU callers
  * create one scene per device (the reference replicates scene + BVH per
  * WebWorker, frontend Renderer.js:213-228,281-297).
  */

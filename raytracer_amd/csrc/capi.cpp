@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 
@@ -46,13 +47,10 @@ rt_status rt_bvh_build(const rt_mesh *mesh, int32_t use_bvh, int32_t max_leaf_si
     *out = nullptr;
     rt_status st = rt::check_mesh(mesh);
     if (st != RT_OK) return st;
-    rt_bvh *b = new rt_bvh;
+    std::unique_ptr<rt_bvh> b(new rt_bvh);
     st = rt::build_bvh(*mesh, use_bvh != 0, max_leaf_size, max_depth, b->bvh);
-    if (st != RT_OK) {
-        delete b;
-        return st;
-    }
-    *out = b;
+    if (st != RT_OK) return st;
+    *out = b.release();
     return RT_OK;
     RT_GUARD_END
 }
@@ -63,13 +61,10 @@ rt_status rt_bvh_from_json(const rt_mesh *mesh, const char *json, size_t len, rt
     *out = nullptr;
     rt_status st = rt::check_mesh(mesh);
     if (st != RT_OK) return st;
-    rt_bvh *b = new rt_bvh;
+    std::unique_ptr<rt_bvh> b(new rt_bvh);
     st = rt::bvh_from_json(*mesh, json, len, b->bvh);
-    if (st != RT_OK) {
-        delete b;
-        return st;
-    }
-    *out = b;
+    if (st != RT_OK) return st;
+    *out = b.release();
     return RT_OK;
     RT_GUARD_END
 }
@@ -102,13 +97,10 @@ rt_status rt_bvh_load(const rt_mesh *mesh, const char *path, rt_bvh **out) {
     *out = nullptr;
     rt_status st = rt::check_mesh(mesh);
     if (st != RT_OK) return st;
-    rt_bvh *b = new rt_bvh;
+    std::unique_ptr<rt_bvh> b(new rt_bvh);
     st = rt::bvh_load(*mesh, path, b->bvh);
-    if (st != RT_OK) {
-        delete b;
-        return st;
-    }
-    *out = b;
+    if (st != RT_OK) return st;
+    *out = b.release();
     return RT_OK;
     RT_GUARD_END
 }
@@ -162,7 +154,7 @@ rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *reco
     rt::FlatScene flat;
     st = rt::flatten(*mesh, bvh->bvh, flat);
     if (st != RT_OK) return st;
-    if (!flat.fast_ok) return fail(RT_ERR_INVALID, "tree does not fit the ordered-traversal encoding (more than 2^24-2 triangles or deeper than 60)");
+    if (!flat.fast_ok) return fail(RT_ERR_INVALID, "tree does not fit the ordered-traversal encoding (more than 2^24-2 triangles, or a wide tree too deep for the traversal stack)");
     *n_records = flat.wide.size() / rtc::kWideFloats;
     *root_ref = flat.fast_root;
     if (records) {
@@ -234,12 +226,11 @@ rt_status rt_scene_create(const rt_mesh *mesh, const rt_bvh *bvh, int32_t device
     if (!bvh) return fail(RT_ERR_STATE, "no BVH: build or load one before creating the scene");
     rt_status st = rt::check_mesh(mesh);
     if (st != RT_OK) return st;
-    rt::Scene *impl = nullptr;
-    st = rt::scene_create(*mesh, bvh->bvh, device, &impl);
+    std::unique_ptr<rt_scene> s(new rt_scene);
+    s->impl = nullptr;
+    st = rt::scene_create(*mesh, bvh->bvh, device, &s->impl);
     if (st != RT_OK) return st;
-    rt_scene *s = new rt_scene;
-    s->impl = impl;
-    *out = s;
+    *out = s.release();
     return RT_OK;
     RT_GUARD_END
 }

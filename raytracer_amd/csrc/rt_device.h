@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "rt_core.h"
@@ -32,7 +33,7 @@ struct PathBuffers {
     float *brdf_terms;         // (B+1)*P*3
     float *radiance;           // P*3, [sample][pixel]
     unsigned long long *ray_total;
-    unsigned long long *trav_counters;   // 5 x u64, filled when the scene counts traversal work
+    unsigned long long *trav_counters;   // 8 x u64, filled when the scene counts traversal work
 };
 
 struct Scene {
@@ -78,6 +79,11 @@ struct Scene {
     std::vector<void *> ws_allocs;
     rtc::TileDesc *d_tiles = nullptr;   // tile table of a multi-tile call
     size_t tile_cap = 0;
+    // The workspace is shared by every render call on this scene: calls take
+    // the mutex on the host, and each call's stream first waits for the event
+    // the previous call recorded at its end, whatever stream that was on.
+    std::mutex render_mu;
+    hipEvent_t ws_done = nullptr;
 };
 
 rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **out);

@@ -841,7 +841,11 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
 
-    std::unique_ptr<Scene> sc(new Scene);
+    // an error return below releases whatever was uploaded so far
+    struct Release {
+        void operator()(Scene *p) const { scene_destroy(p); }
+    };
+    std::unique_ptr<Scene, Release> sc(new Scene);
     sc->device = device;
     sc->n_tris = mesh.n_tris;
     sc->n_nodes = bvh.n_nodes;
@@ -883,6 +887,7 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     }
     if ((st = upload(&sc->d_cursors, nullptr, kCursorSlots * sizeof(uint32_t))) != RT_OK) return st;
     HIP_TRY(hipMemset(sc->d_cursors, 0, kCursorSlots * sizeof(uint32_t)));
+    HIP_TRY(hipEventCreateWithFlags(&sc->ws_done, hipEventDisableTiming));
 
     // default sample tables (same row counts as the reference's)
     std::vector<double> cam((size_t)12345 * 2), lig((size_t)100001 * 2);
@@ -947,6 +952,7 @@ void scene_destroy(Scene *sc) {
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (sc->ws_done) (void)hipEventDestroy(sc->ws_done);
     delete sc;
 }
 
@@ -1197,6 +1203,8 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     if (n_passes > 65536) return fail(RT_ERR_INVALID, "more than 65536 tiles in one call");
     if (!d_accum) return fail(RT_ERR_INVALID, "accumulation buffer is NULL");
     if (sample_begin < 0 || sample_count < 0) return fail(RT_ERR_INVALID, "bad sample range");
+    if (d_rgba && (int64_t)sample_begin + (int64_t)sample_count < 1)
+        return fail(RT_ERR_INVALID, "an image of zero samples cannot be resolved");
     if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64)
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
     const rt_pass &pass = passes[0];
@@ -1221,6 +1229,15 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     }
     if (pixels > 0xffffffffULL) return fail(RT_ERR_INVALID, "more than 2^32-1 pixels in one call");
     const int L = pp.L, B = pp.B;
+
+    // one render call at a time per scene, on the host and on the GPU
+    std::lock_guard<std::mutex> lock(sc.render_mu);
+    HIP_TRY(hipStreamWaitEvent(stream, sc.ws_done, 0));
+    struct MarkDone {
+        Scene &sc;
+        hipStream_t stream;
+        ~MarkDone() { (void)hipEventRecord(sc.ws_done, stream); }
+    } mark_done{sc, stream};
 
     // batch shape: whole pixel rows of the tile-linear range x as many samples as fit
     const size_t max_paths = sc.max_paths_in_flight;
@@ -1349,6 +1366,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
                          float gamma, uint8_t *d_rgba, hipStream_t stream) {
     if (!d_accum || !d_rgba) return fail(RT_ERR_INVALID, "resolve buffers are NULL");
+    if (divisor < 1) return fail(RT_ERR_INVALID, "divisor must be positive");
     if (pixels == 0) return RT_OK;
     const float inv = 1.0f / (float)divisor;
     const double inv_gamma = (double)(1.0f / gamma);

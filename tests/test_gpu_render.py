@@ -243,3 +243,40 @@ def test_batch_shrinks_when_device_memory_is_short(cornell_pair):
         torch.cuda.empty_cache()
     assert st["rays"] > W * H * 2
     assert torch.equal(rgba_a, rgba_b)
+
+
+def test_render_calls_on_one_scene_take_turns(cornell_pair):
+    """Two host threads render different tiles on one scene, each on a stream
+    of its own and without stats (so neither call waits for the GPU): the
+    calls share the scene's path workspace, so the second must wait for the
+    first on the GPU.  Each image equals the one rendered alone."""
+    import threading
+    import torch
+    scene, _ = cornell_pair
+    ds = [scenes.make_pass_dict(250, 250, CORNELL_CAM, spp=3, bounces=3, light_samples=2, seed=s,
+                                x_offset=x, y_offset=60, tile_w=120, tile_h=120, task_id=s)
+          for s, x in ((1, 0), (2, 125))]
+    passes = [api.pass_from_dict(d) for d in ds]
+    alone = [scene.render_tile(p)["rgba"] for p in passes]
+    streams = [torch.cuda.Stream() for _ in passes]
+    accum = [torch.zeros(120 * 120 * 3, dtype=torch.float32, device="cuda") for _ in passes]
+    rgba = [torch.zeros(120 * 120 * 4, dtype=torch.uint8, device="cuda") for _ in passes]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                scene.render_tiles_device([passes[i]], accum[i].data_ptr(), rgba[i].data_ptr(),
+                                          stream=streams[i].cuda_stream)
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        assert np.array_equal(rgba[i].cpu().numpy().reshape(120, 120, 4), alone[i])
