@@ -3,6 +3,7 @@
 // state in an rtb_context instead of package globals.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -140,6 +141,19 @@ rt_status parse_pass(const char *json, rt_pass &p) {
         }
         return v->num;
     };
+    // integer struct fields: encoding/json refuses fractions and values outside the type
+    auto integer = [&](const rtjson::Value &o, const char *name, double lo, double hi) -> double {
+        const double v = num(o, name, 0);
+        if (!(v >= lo && v <= hi) || v != std::floor(v)) {
+            bad = true;
+            bad_name = name;
+            return 0;
+        }
+        return v;
+    };
+    auto int32 = [&](const rtjson::Value &o, const char *name) {
+        return (int32_t)integer(o, name, -2147483648.0, 2147483647.0);
+    };
     auto boolean = [&](const rtjson::Value &o, const char *name) {
         const rtjson::Value *v = o.get(name);
         if (!v || v->is_null()) return false;
@@ -158,8 +172,8 @@ rt_status parse_pass(const char *json, rt_pass &p) {
                 bad_name = "Camera.Transform";
             }
             p.camera.projection_plane_distance = (float)num(*cam, "ProjectionPlaneDistance", 0);
-            p.camera.rays_per_pixel = (int32_t)num(*cam, "RaysPerPixel", 0);
-            p.camera.projection = (int32_t)num(*cam, "Projection", 0);
+            p.camera.rays_per_pixel = int32(*cam, "RaysPerPixel");
+            p.camera.projection = int32(*cam, "Projection");
             p.camera.field_of_view = (float)num(*cam, "FieldOfView", 0);
             p.camera.ortographic_size = (float)num(*cam, "OrtographicSize", 0);
         } else if (!cam->is_null()) {
@@ -167,27 +181,22 @@ rt_status parse_pass(const char *json, rt_pass &p) {
             bad_name = "Camera";
         }
     }
-    p.total_width = (int32_t)num(doc, "TotalWidth", 0);
-    p.total_height = (int32_t)num(doc, "TotalHeight", 0);
-    p.task_id = (int32_t)num(doc, "TaskID", 0);
-    p.rng_seed = (int64_t)num(doc, "RNGSeed", 0);
-    p.x_offset = (int32_t)num(doc, "XOffset", 0);
-    p.y_offset = (int32_t)num(doc, "YOffset", 0);
-    p.width = (int32_t)num(doc, "Width", 0);
-    p.height = (int32_t)num(doc, "Height", 0);
-    p.render_key = (int32_t)num(doc, "RenderKey", 0);
+    p.total_width = int32(doc, "TotalWidth");
+    p.total_height = int32(doc, "TotalHeight");
+    p.task_id = int32(doc, "TaskID");
+    p.rng_seed = (int64_t)integer(doc, "RNGSeed", -9223372036854775808.0, 9223372036854774784.0);
+    p.x_offset = int32(doc, "XOffset");
+    p.y_offset = int32(doc, "YOffset");
+    p.width = int32(doc, "Width");
+    p.height = int32(doc, "Height");
+    p.render_key = int32(doc, "RenderKey");
     if (const rtjson::Value *s = doc.get("Settings")) {
         if (s->kind == rtjson::Value::Object) {
             p.settings.draw_surface_normal = boolean(*s, "DrawSurfaceNormal");
             p.settings.gamma_correction = boolean(*s, "GammaCorrection");
             p.settings.gamma = (float)num(*s, "Gamma", 0);
-            p.settings.light_sample_rays = (int32_t)num(*s, "LightSampleRays", 0);
-            const double bl = num(*s, "BounceLimit", 0);
-            if (bl < 0 || bl > 255) {   // uint8 in the reference
-                bad = true;
-                bad_name = "Settings.BounceLimit";
-            }
-            p.settings.bounce_limit = (int32_t)bl;
+            p.settings.light_sample_rays = int32(*s, "LightSampleRays");
+            p.settings.bounce_limit = (int32_t)integer(*s, "BounceLimit", 0, 255);   // uint8 in the reference
             p.settings.light_intensity = (float)num(*s, "LightIntensity", 0);
             p.settings.debug_light_size = (float)num(*s, "DebugLightSize", 0);
             p.settings.force_debug_light = boolean(*s, "ForceDebugLight");
@@ -280,9 +289,15 @@ rt_status rtb_initialize(rtb_context *ctx, const char *context_json, const uint8
     ctx->rays = 0;   // context.go:57
     ctx->debug = doc.bool_or("Debug", false);
     ctx->use_bvh = doc.bool_or("UseBVH", false);
-    ctx->max_leaf = (int32_t)doc.number_or("BVHMaxLeafSize", 0);
-    ctx->max_depth = (int32_t)doc.number_or("BVHMaxDepth", 0);
-    ctx->worker_id = (int32_t)doc.number_or("WorkerId", 0);
+    auto int_field = [&](const char *name, int32_t &out) {   // encoding/json: a Go int takes whole numbers only
+        const double v = doc.number_or(name, 0);
+        if (!(v >= -2147483648.0 && v <= 2147483647.0) || v != std::floor(v)) return false;
+        out = (int32_t)v;
+        return true;
+    };
+    if (!int_field("BVHMaxLeafSize", ctx->max_leaf) || !int_field("BVHMaxDepth", ctx->max_depth) ||
+        !int_field("WorkerId", ctx->worker_id))
+        return fail(RT_ERR_PARSE, "render context: BVHMaxLeafSize, BVHMaxDepth and WorkerId must be whole numbers");
     const std::string obj = doc.string_or("ObjBuffer", ""), mtl = doc.string_or("MtlBuffer", "");
     send_progress(ctx, 0.0f, "RenderContext.Initialize", -1);
     if (obj.empty() || mtl.empty())
@@ -297,7 +312,7 @@ rt_status rtb_initialize(rtb_context *ctx, const char *context_json, const uint8
             for (size_t i = 0; i < raw->arr.size(); ++i) {
                 rtb_context::Texture t;
                 t.name = raw->arr[i].string_or("Name", "");
-                if ((int32_t)i >= n_textures || !textures || !textures[i])
+                if ((int32_t)i >= n_textures || !textures || !texture_sizes || !textures[i])
                     return fail(RT_ERR_INVALID, "render context: no bytes given for texture '" + t.name + "'");
                 st = rt::decode_png(textures[i], texture_sizes[i], t.rgba, t.w, t.h);
                 if (st != RT_OK) return st;

@@ -103,6 +103,17 @@ def test_render_errors_come_back_as_documents(product_lib):
         assert img.shape == (500, 500, 4) and not img.any()
     doc = json.loads(b.incrementalRender())
     assert doc["exitCode"] == -1 and "initializeIncrementalRender" in doc["message"]
+    # encoding/json refuses fractions and out-of-range values for integer fields
+    good = _tasks(1)[0]
+    for field, value in (("Width", 62.5), ("TaskID", 1e30), ("XOffset", -3e9), ("RNGSeed", 0.5)):
+        doc = json.loads(b.render(json.dumps(dict(good, **{field: value}))))
+        assert doc["exitCode"] == -1 and field in doc["message"], (field, doc["message"])
+    for field, value in (("BounceLimit", 256), ("BounceLimit", 1.5), ("LightSampleRays", 2.5)):
+        bad = dict(good, Settings=dict(good["Settings"], **{field: value}))
+        doc = json.loads(b.render(json.dumps(bad)))
+        assert doc["exitCode"] == -1 and field in doc["message"], (field, doc["message"])
+    with pytest.raises(api._capi.RtError):
+        b.initialize(_context_json(BVHMaxDepth=16.5))
 
 
 def _png(w, h, ctype, rows, palette=None, trns=None, depth=8):
