@@ -77,7 +77,9 @@ struct Huffman {
     }
 };
 
-bool inflate(const uint8_t *data, size_t size, std::vector<uint8_t> &out) {
+// Inflates until the stream ends or `limit` bytes are out (what the image
+// needs; a stream that expands further is not followed).
+bool inflate(const uint8_t *data, size_t size, std::vector<uint8_t> &out, size_t limit) {
     if (size < 2) return false;
     BitReader br{data + 2, data + size};   // skip the zlib header
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -142,6 +144,7 @@ bool inflate(const uint8_t *data, size_t size, std::vector<uint8_t> &out) {
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) return false;
+                if (out.size() >= limit) break;
                 if (sym < 256) {
                     out.push_back((uint8_t)sym);
                 } else if (sym == 256) {
@@ -161,7 +164,7 @@ bool inflate(const uint8_t *data, size_t size, std::vector<uint8_t> &out) {
         } else {
             return false;
         }
-        if (last) break;
+        if (last || out.size() >= limit) break;
     }
     return true;
 }
@@ -230,8 +233,11 @@ rt_status decode_png(const uint8_t *data, size_t size, std::vector<uint8_t> &rgb
     const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
     const size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
     std::vector<uint8_t> raw;
-    raw.reserve((stride + 1) * h);
-    if (!inflate(idat.data(), idat.size(), raw) || raw.size() < (stride + 1) * (size_t)h)
+    const size_t need = (stride + 1) * (size_t)h;
+    // deflate expands at most 1032-fold: a short stream cannot fill a large image
+    if (idat.size() < need / 1032) return fail(RT_ERR_PARSE, "corrupt PNG data stream");
+    raw.reserve(need + 258);
+    if (!inflate(idat.data(), idat.size(), raw, need) || raw.size() < need)
         return fail(RT_ERR_PARSE, "corrupt PNG data stream");
     // undo the row filters in place
     std::vector<uint8_t> prev(stride, 0);

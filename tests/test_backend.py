@@ -157,6 +157,14 @@ def test_png_decoding(product_lib):
         api.png_decode(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
     with pytest.raises(api._capi.RtError):
         api.png_decode(b"GIF89a" + b"\0" * 40)
+    # a header that promises far more pixels than the data stream can hold is refused
+    # before anything of that size is allocated; extra data after the image is ignored
+    tiny = _png(4, 4, 2, [[7] * 12] * 4)
+    huge = tiny[:16] + struct.pack(">II", 60000, 60000) + tiny[24:29]
+    huge += struct.pack(">I", zlib.crc32(huge[12:29])) + tiny[33:]
+    with pytest.raises(api._capi.RtError):
+        api.png_decode(huge)
+    assert (api.png_decode(_png(4, 4, 2, [[7] * 12] * 9))[..., :3] == 7).all()
 
 
 @pytest.mark.gpu
