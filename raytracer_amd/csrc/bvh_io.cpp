@@ -196,8 +196,11 @@ rt_status bvh_from_json(const rt_mesh &mesh, const char *json, size_t len, Bvh &
         if (!ok) return fail(RT_ERR_PARSE, "BVH JSON node without usable Bounds");
         read_vec(n->get("SplitPlane"), split, 4);
         out.is_leaf.push_back(has_l ? 0 : 1);
-        out.start.push_back((int32_t)n->number_or("StartIndex", 0));
-        out.end.push_back((int32_t)n->number_or("EndIndex", -1));
+        const double si = n->number_or("StartIndex", 0), ei = n->number_or("EndIndex", -1);
+        if (!(si >= -1 && si <= 2147483647.0 && ei >= -1 && ei <= 2147483647.0))
+            return fail(RT_ERR_PARSE, "BVH JSON node with an index outside the int range");
+        out.start.push_back((int32_t)si);
+        out.end.push_back((int32_t)ei);
         out.depth.push_back(depth);
         out.max_depth = std::max(out.max_depth, depth);
         for (int k = 0; k < 3; ++k) {

@@ -923,6 +923,7 @@ rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_
         sc.tex_dims.resize(2 * ((size_t)slot + 1), 0);
     }
     if (sc.tex_ptrs[(size_t)slot]) (void)hipFree(sc.tex_ptrs[(size_t)slot]);
+    sc.tex_ptrs[(size_t)slot] = nullptr;
     uint8_t *d = nullptr;
     rt_status st;
     if ((st = upload(&d, rgba, (size_t)w * (size_t)h * 4)) != RT_OK) return st;
@@ -931,8 +932,17 @@ rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_
     sc.tex_dims[2 * (size_t)slot + 1] = h;
     if (sc.d_tex_ptrs) (void)hipFree(sc.d_tex_ptrs);
     if (sc.d_tex_dims) (void)hipFree(sc.d_tex_dims);
+    sc.d_tex_ptrs = nullptr;
+    sc.d_tex_dims = nullptr;
     if ((st = upload(&sc.d_tex_ptrs, sc.tex_ptrs.data(), sc.tex_ptrs.size() * sizeof(uint8_t *))) != RT_OK) return st;
     if ((st = upload(&sc.d_tex_dims, sc.tex_dims.data(), sc.tex_dims.size() * 4)) != RT_OK) return st;
+    // the kernels index the slot tables with the material's texture id: ids
+    // without an image so far read as "no texture"
+    std::vector<int32_t> usable(sc.mat_tex);
+    for (int32_t &id : usable)
+        if (id < 0 || (size_t)id >= sc.tex_ptrs.size() || !sc.tex_ptrs[(size_t)id]) id = -1;
+    if (!usable.empty())
+        HIP_TRY(hipMemcpy(sc.d_mat_tex, usable.data(), usable.size() * 4, hipMemcpyHostToDevice));
     return RT_OK;
 }
 
