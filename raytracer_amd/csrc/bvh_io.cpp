@@ -8,9 +8,11 @@
 //         (the reference keeps the JSON in the browser's IndexedDB,
 //         frontend Renderer.js:235-274).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <thread>
 
 #include "json.h"
 #include "rt_internal.h"
@@ -99,15 +101,6 @@ void write_node(const Bvh &b, const std::vector<int32_t> &size, int32_t i, std::
     }
 }
 
-bool read_vec(const rtjson::Value *v, float *out, int n) {
-    if (!v || v->kind != rtjson::Value::Array || (int)v->arr.size() != n) return false;
-    for (int i = 0; i < n; ++i) {
-        if (v->arr[(size_t)i].kind != rtjson::Value::Number) return false;
-        out[i] = (float)v->arr[(size_t)i].num;
-    }
-    return true;
-}
-
 }  // namespace
 
 rt_status bvh_to_json(const Bvh &b, std::string &out) {
@@ -153,64 +146,294 @@ static void sort_range(const rt_mesh &mesh, std::vector<int32_t> &order, int32_t
 }
 
 // BVH.Load: sort every interior node's range by its stored plane, parents
-// before children.
+// before children.  A child's range lies inside its parent's and the ranges of
+// nodes at one depth do not overlap (checked below; a tree that breaks this is
+// sorted node by node in preorder instead), so the nodes of one depth are
+// sorted on several threads, depth by depth.
 static rt_status resort_from_planes(const rt_mesh &mesh, Bvh &b) {
     b.order.resize((size_t)mesh.n_tris);
     for (int32_t i = 0; i < mesh.n_tris; ++i) b.order[(size_t)i] = i;
+    std::vector<std::vector<int32_t>> by_depth;
     for (int32_t n = 0; n < b.n_nodes; ++n) {
         const int32_t s = b.start[(size_t)n], e = b.end[(size_t)n];
         if (e >= mesh.n_tris || s < 0)
             return fail(RT_ERR_INVALID, "BVH node " + std::to_string(n) + " indexes outside the triangle array");
-        if (!b.is_leaf[(size_t)n]) sort_range(mesh, b.order, s, e, &b.split[4 * (size_t)n]);
+        if (b.is_leaf[(size_t)n]) continue;
+        const size_t d = (size_t)b.depth[(size_t)n];
+        if (d >= by_depth.size()) by_depth.resize(d + 1);
+        by_depth[d].push_back(n);
+    }
+    bool disjoint = true;   // preorder within a depth is left to right: ranges must ascend
+    for (const auto &level : by_depth)
+        for (size_t i = 1; i < level.size() && disjoint; ++i)
+            if (b.start[(size_t)level[i]] <= b.end[(size_t)level[i - 1]]) disjoint = false;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
+    if (!disjoint || n_threads < 2 || mesh.n_tris < 50000) {
+        for (int32_t n = 0; n < b.n_nodes; ++n)
+            if (!b.is_leaf[(size_t)n])
+                sort_range(mesh, b.order, b.start[(size_t)n], b.end[(size_t)n], &b.split[4 * (size_t)n]);
+        return RT_OK;
+    }
+    for (const auto &level : by_depth) {
+        if (level.size() < 2) {
+            for (int32_t n : level)
+                sort_range(mesh, b.order, b.start[(size_t)n], b.end[(size_t)n], &b.split[4 * (size_t)n]);
+            continue;
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < level.size(); i = next.fetch_add(1)) {
+                const int32_t n = level[i];
+                sort_range(mesh, b.order, b.start[(size_t)n], b.end[(size_t)n], &b.split[4 * (size_t)n]);
+            }
+        };
+        const int use = (int)std::min<size_t>((size_t)n_threads, level.size());
+        std::vector<std::thread> pool;
+        for (int t = 1; t < use; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
     }
     return RT_OK;
 }
 
+namespace {
+
+// One BVHNode of the hand-over text, as read: the tree of a million triangles
+// is a 110 MB document, so it is read token by token into these 64-byte
+// structs instead of a DOM.
+struct TextNode {
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, split[4] = {0, 0, 0, 0};
+    int32_t start = 0, end = -1, left = -1, right = -1;
+    bool have_bounds = false;
+};
+
+class TreeReader {
+  public:
+    TreeReader(const char *s, size_t n) : lx(s, n) {}
+    rtjson::Lexer lx;
+    std::vector<TextNode> nodes;
+    std::string problem;   // set when the text is valid JSON but not a usable tree
+
+    // `n` numbers in an array; anything else is stepped over and reported as unusable
+    bool numbers(float *out, int n, bool &usable) {
+        usable = false;
+        if (lx.peek() != '[') return lx.skip_value();
+        lx.consume('[');
+        int count = 0;
+        bool bad = false;
+        if (!lx.consume(']')) {
+            for (;;) {
+                const char c = lx.peek();
+                if (c == '-' || (c >= '0' && c <= '9')) {
+                    double d;
+                    if (!lx.number(d)) return false;
+                    if (count < n) out[count] = (float)d;
+                    ++count;
+                } else {
+                    bad = true;
+                    if (!lx.skip_value()) return false;
+                }
+                if (lx.consume(',')) continue;
+                if (lx.consume(']')) break;
+                return lx.fail("expected ',' or ']'");
+            }
+        }
+        usable = !bad && count == n;
+        return true;
+    }
+    bool index(int32_t &out) {
+        const char c = lx.peek();
+        if (!(c == '-' || (c >= '0' && c <= '9'))) return lx.skip_value();   // wrong type: keeps the default
+        double d;
+        if (!lx.number(d)) return false;
+        if (!(d >= -1 && d <= 2147483647.0)) {
+            if (problem.empty()) problem = "BVH JSON node with an index outside the int range";
+            return true;
+        }
+        out = (int32_t)d;
+        return true;
+    }
+    // models.AABB: "Bounds":[min,max] first, else "Min" and "Max"
+    bool bounds(TextNode &nd) {
+        if (lx.peek() != '{') return lx.skip_value();
+        lx.consume('{');
+        float pair_mn[3], pair_mx[3], mn[3], mx[3];
+        bool pair_ok = false, mn_ok = false, mx_ok = false;
+        std::string key;
+        if (!lx.consume('}')) {
+            for (;;) {
+                if (!lx.string(key)) return false;
+                if (!lx.consume(':')) return lx.fail("expected ':'");
+                if (rtjson::key_is(key, "Bounds")) {
+                    pair_ok = false;
+                    if (lx.peek() != '[') {
+                        if (!lx.skip_value()) return false;
+                    } else {
+                        lx.consume('[');
+                        int count = 0;
+                        bool a = false, b = false, extra = false;
+                        if (!lx.consume(']')) {
+                            for (;;) {
+                                bool ok = false;
+                                if (count == 0) {
+                                    if (!numbers(pair_mn, 3, ok)) return false;
+                                    a = ok;
+                                } else if (count == 1) {
+                                    if (!numbers(pair_mx, 3, ok)) return false;
+                                    b = ok;
+                                } else {
+                                    extra = true;
+                                    if (!lx.skip_value()) return false;
+                                }
+                                ++count;
+                                if (lx.consume(',')) continue;
+                                if (lx.consume(']')) break;
+                                return lx.fail("expected ',' or ']'");
+                            }
+                        }
+                        pair_ok = a && b && !extra;
+                    }
+                } else if (rtjson::key_is(key, "Min")) {
+                    if (!numbers(mn, 3, mn_ok)) return false;
+                } else if (rtjson::key_is(key, "Max")) {
+                    if (!numbers(mx, 3, mx_ok)) return false;
+                } else if (!lx.skip_value()) {
+                    return false;
+                }
+                if (lx.consume(',')) continue;
+                if (lx.consume('}')) break;
+                return lx.fail("expected ',' or '}'");
+            }
+        }
+        if (pair_ok) {
+            std::memcpy(nd.mn, pair_mn, 12);
+            std::memcpy(nd.mx, pair_mx, 12);
+            nd.have_bounds = true;
+        } else if (mn_ok && mx_ok) {
+            std::memcpy(nd.mn, mn, 12);
+            std::memcpy(nd.mx, mx, 12);
+            nd.have_bounds = true;
+        }
+        return true;
+    }
+    // A BVHNode object; returns its index in `nodes`, -1 for anything that is not
+    // an object (null, or a value of another type), -2 on a syntax error.
+    int32_t node(int depth) {
+        if (depth > 2000) {
+            lx.fail("BVH JSON nested too deeply");
+            return -2;
+        }
+        if (lx.peek() != '{') return lx.skip_value() ? -1 : -2;
+        lx.consume('{');
+        const int32_t id = (int32_t)nodes.size();
+        nodes.emplace_back();
+        std::string key;
+        if (lx.consume('}')) return id;
+        for (;;) {
+            if (!lx.string(key)) return -2;
+            if (!lx.consume(':')) {
+                lx.fail("expected ':'");
+                return -2;
+            }
+            if (rtjson::key_is(key, "LeftChild") || rtjson::key_is(key, "RightChild")) {
+                const int32_t child = node(depth + 1);
+                if (child == -2) return -2;
+                if (rtjson::key_is(key, "LeftChild")) nodes[(size_t)id].left = child;
+                else nodes[(size_t)id].right = child;
+            } else if (rtjson::key_is(key, "Bounds")) {
+                TextNode nd = nodes[(size_t)id];
+                if (!bounds(nd)) return -2;
+                nodes[(size_t)id] = nd;
+            } else if (rtjson::key_is(key, "StartIndex")) {
+                if (!index(nodes[(size_t)id].start)) return -2;
+            } else if (rtjson::key_is(key, "EndIndex")) {
+                if (!index(nodes[(size_t)id].end)) return -2;
+            } else if (rtjson::key_is(key, "SplitPlane")) {
+                float sp[4] = {0, 0, 0, 0};
+                bool ok = false;
+                if (!numbers(sp, 4, ok)) return -2;
+                if (ok) std::memcpy(nodes[(size_t)id].split, sp, 16);
+            } else if (!lx.skip_value()) {
+                return -2;
+            }
+            if (lx.consume(',')) continue;
+            if (lx.consume('}')) return id;
+            lx.fail("expected ',' or '}'");
+            return -2;
+        }
+    }
+    // the document: {"Root": node}
+    bool document(int32_t &root) {
+        root = -1;
+        if (lx.peek() != '{') {
+            if (!lx.skip_value()) return false;
+            return lx.at_end() || lx.fail("trailing characters after JSON value");
+        }
+        lx.consume('{');
+        std::string key;
+        if (!lx.consume('}')) {
+            for (;;) {
+                if (!lx.string(key)) return false;
+                if (!lx.consume(':')) return lx.fail("expected ':'");
+                if (rtjson::key_is(key, "Root")) {
+                    nodes.clear();
+                    root = node(0);
+                    if (root == -2) return false;
+                } else if (!lx.skip_value()) {
+                    return false;
+                }
+                if (lx.consume(',')) continue;
+                if (lx.consume('}')) break;
+                return lx.fail("expected ',' or '}'");
+            }
+        }
+        return lx.at_end() || lx.fail("trailing characters after JSON value");
+    }
+};
+
+}  // namespace
+
 rt_status bvh_from_json(const rt_mesh &mesh, const char *json, size_t len, Bvh &out) {
-    rtjson::Value doc;
-    std::string err;
-    if (!rtjson::parse(json, len, doc, err)) return fail(RT_ERR_PARSE, "BVH JSON: " + err);
-    const rtjson::Value *root = doc.get("Root");
-    if (!root || root->kind != rtjson::Value::Object) return fail(RT_ERR_PARSE, "BVH JSON has no Root object");
+    TreeReader reader(json, len);
+    int32_t root = -1;
+    if (!reader.document(root))
+        return fail(RT_ERR_PARSE, "BVH JSON: " + (reader.lx.error().empty() ? std::string("invalid JSON") : reader.lx.error()));
+    if (root < 0) return fail(RT_ERR_PARSE, "BVH JSON has no Root object");
+    if (!reader.problem.empty()) return fail(RT_ERR_PARSE, reader.problem);
+    const std::vector<TextNode> &tn = reader.nodes;
     out = Bvh();
     out.n_tris = mesh.n_tris;
-    std::vector<std::pair<const rtjson::Value *, int32_t>> st;   // preorder walk, depth recomputed
+    const size_t total = tn.size();
+    out.is_leaf.reserve(total);
+    out.start.reserve(total);
+    out.end.reserve(total);
+    out.depth.reserve(total);
+    out.bmin.reserve(3 * total);
+    out.bmax.reserve(3 * total);
+    out.split.reserve(4 * total);
+    std::vector<std::pair<int32_t, int32_t>> st;   // preorder walk, depth recomputed
     st.emplace_back(root, 0);
     while (!st.empty()) {
-        const rtjson::Value *n = st.back().first;
+        const TextNode &n = tn[(size_t)st.back().first];
         const int32_t depth = st.back().second;
         st.pop_back();
-        const rtjson::Value *l = n->get("LeftChild"), *r = n->get("RightChild");
-        const bool has_l = l && l->kind == rtjson::Value::Object;
-        const bool has_r = r && r->kind == rtjson::Value::Object;
+        const bool has_l = n.left >= 0, has_r = n.right >= 0;
         if (has_l != has_r) return fail(RT_ERR_PARSE, "BVH JSON node with a single child");
-        float mn[3], mx[3], split[4] = {0, 0, 0, 0};
-        const rtjson::Value *bounds = n->get("Bounds");
-        bool ok = false;
-        if (bounds && bounds->kind == rtjson::Value::Object) {
-            const rtjson::Value *bb = bounds->get("Bounds");
-            if (bb && bb->kind == rtjson::Value::Array && bb->arr.size() == 2)
-                ok = read_vec(&bb->arr[0], mn, 3) && read_vec(&bb->arr[1], mx, 3);
-            if (!ok) ok = read_vec(bounds->get("Min"), mn, 3) && read_vec(bounds->get("Max"), mx, 3);
-        }
-        if (!ok) return fail(RT_ERR_PARSE, "BVH JSON node without usable Bounds");
-        read_vec(n->get("SplitPlane"), split, 4);
+        if (!n.have_bounds) return fail(RT_ERR_PARSE, "BVH JSON node without usable Bounds");
         out.is_leaf.push_back(has_l ? 0 : 1);
-        const double si = n->number_or("StartIndex", 0), ei = n->number_or("EndIndex", -1);
-        if (!(si >= -1 && si <= 2147483647.0 && ei >= -1 && ei <= 2147483647.0))
-            return fail(RT_ERR_PARSE, "BVH JSON node with an index outside the int range");
-        out.start.push_back((int32_t)si);
-        out.end.push_back((int32_t)ei);
+        out.start.push_back(n.start);
+        out.end.push_back(n.end);
         out.depth.push_back(depth);
         out.max_depth = std::max(out.max_depth, depth);
         for (int k = 0; k < 3; ++k) {
-            out.bmin.push_back(mn[k]);
-            out.bmax.push_back(mx[k]);
+            out.bmin.push_back(n.mn[k]);
+            out.bmax.push_back(n.mx[k]);
         }
-        for (int k = 0; k < 4; ++k) out.split.push_back(split[k]);
+        for (int k = 0; k < 4; ++k) out.split.push_back(n.split[k]);
         if (has_l) {
-            st.emplace_back(r, depth + 1);
-            st.emplace_back(l, depth + 1);
+            st.emplace_back(n.right, depth + 1);
+            st.emplace_back(n.left, depth + 1);
         }
     }
     out.n_nodes = (int32_t)out.is_leaf.size();

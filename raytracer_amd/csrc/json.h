@@ -56,71 +56,45 @@ struct Value {
     }
 };
 
-class Parser {
+// Token-level reader: the primitives the DOM parser below is made of, also used
+// directly where a document is too large for a DOM (the BVH hand-over text).
+class Lexer {
   public:
-    Parser(const char *s, size_t n) : p_(s), end_(s + n) {}
-    bool parse(Value &out, std::string &err) {
-        skip_ws();
-        if (!value(out, 0)) {
-            err = err_.empty() ? "invalid JSON" : err_;
-            return false;
-        }
-        skip_ws();
-        if (p_ != end_) {
-            err = "trailing characters after JSON value";
-            return false;
-        }
-        return true;
-    }
-
-  private:
-    const char *p_, *end_;
-    std::string err_;
-
-    void skip_ws() {
-        while (p_ < end_ && (*p_ == ' ' || *p_ == '\t' || *p_ == '\n' || *p_ == '\r')) ++p_;
-    }
+    Lexer(const char *s, size_t n) : p_(s), end_(s + n) {}
+    const std::string &error() const { return err_; }
     bool fail(const char *m) {
         if (err_.empty()) err_ = m;
         return false;
     }
+    void skip_ws() {
+        while (p_ < end_ && (*p_ == ' ' || *p_ == '\t' || *p_ == '\n' || *p_ == '\r')) ++p_;
+    }
+    bool at_end() {
+        skip_ws();
+        return p_ == end_;
+    }
+    // next significant character, 0 at the end of the text
+    char peek() {
+        skip_ws();
+        return p_ < end_ ? *p_ : '\0';
+    }
+    bool consume(char c) {
+        skip_ws();
+        if (p_ < end_ && *p_ == c) {
+            ++p_;
+            return true;
+        }
+        return false;
+    }
     bool literal(const char *lit) {
+        skip_ws();
         size_t n = std::strlen(lit);
         if ((size_t)(end_ - p_) < n || std::memcmp(p_, lit, n) != 0) return fail("invalid literal");
         p_ += n;
         return true;
     }
-    static void put_utf8(std::string &s, unsigned cp) {
-        if (cp < 0x80) {
-            s.push_back((char)cp);
-        } else if (cp < 0x800) {
-            s.push_back((char)(0xC0 | (cp >> 6)));
-            s.push_back((char)(0x80 | (cp & 0x3F)));
-        } else if (cp < 0x10000) {
-            s.push_back((char)(0xE0 | (cp >> 12)));
-            s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
-            s.push_back((char)(0x80 | (cp & 0x3F)));
-        } else {
-            s.push_back((char)(0xF0 | (cp >> 18)));
-            s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
-            s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
-            s.push_back((char)(0x80 | (cp & 0x3F)));
-        }
-    }
-    bool hex4(unsigned &out) {
-        if (end_ - p_ < 4) return fail("short \\u escape");
-        out = 0;
-        for (int i = 0; i < 4; ++i) {
-            char c = *p_++;
-            out <<= 4;
-            if (c >= '0' && c <= '9') out |= (unsigned)(c - '0');
-            else if (c >= 'a' && c <= 'f') out |= (unsigned)(c - 'a' + 10);
-            else if (c >= 'A' && c <= 'F') out |= (unsigned)(c - 'A' + 10);
-            else return fail("bad \\u escape");
-        }
-        return true;
-    }
     bool string(std::string &out) {
+        skip_ws();
         if (p_ >= end_ || *p_ != '"') return fail("expected string");
         ++p_;
         out.clear();
@@ -164,93 +138,179 @@ class Parser {
         }
         return fail("unterminated string");
     }
-    bool value(Value &out, int depth) {
-        if (depth > 4096) return fail("JSON nested too deeply");
+    bool number(double &out) {
         skip_ws();
-        if (p_ >= end_) return fail("unexpected end of JSON");
-        char c = *p_;
+        const char *q = p_;
+        if (q < end_ && *q == '-') ++q;
+        if (q >= end_ || *q < '0' || *q > '9') return fail("expected number");
+        while (q < end_ && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) ++q;
+        // from_chars takes no leading '+', like JSON; it must consume the whole token
+        const auto r = std::from_chars(p_, q, out);
+        if (r.ec != std::errc() || r.ptr != q) return fail("bad number");
+        p_ = q;
+        return true;
+    }
+    // Steps over one value of any kind, checking its syntax.
+    bool skip_value(int depth = 0) {
+        if (depth > 4096) return fail("JSON nested too deeply");
+        const char c = peek();
         if (c == '{') {
             ++p_;
-            out.kind = Value::Object;
-            skip_ws();
-            if (p_ < end_ && *p_ == '}') {
-                ++p_;
-                return true;
-            }
+            if (consume('}')) return true;
+            std::string key;
             for (;;) {
-                skip_ws();
-                std::string key;
                 if (!string(key)) return false;
-                skip_ws();
-                if (p_ >= end_ || *p_ != ':') return fail("expected ':'");
-                ++p_;
-                out.obj.emplace_back(std::move(key), Value());
-                if (!value(out.obj.back().second, depth + 1)) return false;
-                skip_ws();
-                if (p_ < end_ && *p_ == ',') {
-                    ++p_;
-                    continue;
-                }
-                if (p_ < end_ && *p_ == '}') {
-                    ++p_;
-                    return true;
-                }
+                if (!consume(':')) return fail("expected ':'");
+                if (!skip_value(depth + 1)) return false;
+                if (consume(',')) continue;
+                if (consume('}')) return true;
                 return fail("expected ',' or '}'");
             }
         }
         if (c == '[') {
             ++p_;
-            out.kind = Value::Array;
-            skip_ws();
-            if (p_ < end_ && *p_ == ']') {
-                ++p_;
-                return true;
-            }
+            if (consume(']')) return true;
             for (;;) {
-                out.arr.emplace_back();
-                if (!value(out.arr.back(), depth + 1)) return false;
-                skip_ws();
-                if (p_ < end_ && *p_ == ',') {
-                    ++p_;
-                    continue;
-                }
-                if (p_ < end_ && *p_ == ']') {
-                    ++p_;
-                    return true;
-                }
+                if (!skip_value(depth + 1)) return false;
+                if (consume(',')) continue;
+                if (consume(']')) return true;
                 return fail("expected ',' or ']'");
             }
         }
         if (c == '"') {
+            std::string s;
+            return string(s);
+        }
+        if (c == 't') return literal("true");
+        if (c == 'f') return literal("false");
+        if (c == 'n') return literal("null");
+        if (c == '-' || (c >= '0' && c <= '9')) {
+            double d;
+            return number(d);
+        }
+        return fail(c == '\0' ? "unexpected end of JSON" : "unexpected character in JSON");
+    }
+
+  private:
+    const char *p_, *end_;
+    std::string err_;
+
+    static void put_utf8(std::string &s, unsigned cp) {
+        if (cp < 0x80) {
+            s.push_back((char)cp);
+        } else if (cp < 0x800) {
+            s.push_back((char)(0xC0 | (cp >> 6)));
+            s.push_back((char)(0x80 | (cp & 0x3F)));
+        } else if (cp < 0x10000) {
+            s.push_back((char)(0xE0 | (cp >> 12)));
+            s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            s.push_back((char)(0x80 | (cp & 0x3F)));
+        } else {
+            s.push_back((char)(0xF0 | (cp >> 18)));
+            s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+            s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            s.push_back((char)(0x80 | (cp & 0x3F)));
+        }
+    }
+    bool hex4(unsigned &out) {
+        if (end_ - p_ < 4) return fail("short \\u escape");
+        out = 0;
+        for (int i = 0; i < 4; ++i) {
+            char c = *p_++;
+            out <<= 4;
+            if (c >= '0' && c <= '9') out |= (unsigned)(c - '0');
+            else if (c >= 'a' && c <= 'f') out |= (unsigned)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') out |= (unsigned)(c - 'A' + 10);
+            else return fail("bad \\u escape");
+        }
+        return true;
+    }
+};
+
+// ASCII case-insensitive comparison: encoding/json matches struct fields this
+// way when no exact match exists.
+inline bool key_is(const std::string &key, const char *name) {
+    const size_t n = std::strlen(name);
+    if (key.size() != n) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (std::tolower((unsigned char)key[i]) != std::tolower((unsigned char)name[i])) return false;
+    return true;
+}
+
+class Parser {
+  public:
+    Parser(const char *s, size_t n) : lx_(s, n) {}
+    bool parse(Value &out, std::string &err) {
+        if (!value(out, 0)) {
+            err = lx_.error().empty() ? "invalid JSON" : lx_.error();
+            return false;
+        }
+        if (!lx_.at_end()) {
+            err = "trailing characters after JSON value";
+            return false;
+        }
+        return true;
+    }
+
+  private:
+    Lexer lx_;
+
+    bool value(Value &out, int depth) {
+        if (depth > 4096) return lx_.fail("JSON nested too deeply");
+        const char c = lx_.peek();
+        if (c == '\0') return lx_.fail("unexpected end of JSON");
+        if (c == '{') {
+            lx_.consume('{');
+            out.kind = Value::Object;
+            if (lx_.consume('}')) return true;
+            out.obj.reserve(8);
+            for (;;) {
+                std::string key;
+                if (!lx_.string(key)) return false;
+                if (!lx_.consume(':')) return lx_.fail("expected ':'");
+                out.obj.emplace_back(std::move(key), Value());
+                if (!value(out.obj.back().second, depth + 1)) return false;
+                if (lx_.consume(',')) continue;
+                if (lx_.consume('}')) return true;
+                return lx_.fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            lx_.consume('[');
+            out.kind = Value::Array;
+            if (lx_.consume(']')) return true;
+            out.arr.reserve(4);
+            for (;;) {
+                out.arr.emplace_back();
+                if (!value(out.arr.back(), depth + 1)) return false;
+                if (lx_.consume(',')) continue;
+                if (lx_.consume(']')) return true;
+                return lx_.fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') {
             out.kind = Value::String;
-            return string(out.str);
+            return lx_.string(out.str);
         }
         if (c == 't') {
             out.kind = Value::Bool;
             out.b = true;
-            return literal("true");
+            return lx_.literal("true");
         }
         if (c == 'f') {
             out.kind = Value::Bool;
             out.b = false;
-            return literal("false");
+            return lx_.literal("false");
         }
         if (c == 'n') {
             out.kind = Value::Null;
-            return literal("null");
+            return lx_.literal("null");
         }
         if (c == '-' || (c >= '0' && c <= '9')) {
-            const char *q = p_;
-            if (*q == '-') ++q;
-            while (q < end_ && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) ++q;
-            // from_chars takes no leading '+', like JSON; it must consume the whole token
-            const auto r = std::from_chars(p_, q, out.num);
-            if (r.ec != std::errc() || r.ptr != q) return fail("bad number");
             out.kind = Value::Number;
-            p_ = q;
-            return true;
+            return lx_.number(out.num);
         }
-        return fail("unexpected character in JSON");
+        return lx_.fail("unexpected character in JSON");
     }
 };
 

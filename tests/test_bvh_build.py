@@ -82,6 +82,32 @@ def test_json_round_trip_and_reference_schema(product_lib):
     assert _same(b.export(), b3.export())
 
 
+def test_json_reader_takes_any_member_order_and_unknown_members(product_lib):
+    """The hand-over text is read token by token; what encoding/json accepts must
+    still load: members in any order, other spellings of the case, unknown
+    members of any shape, Min/Max without the [min,max] pair, white space."""
+    sc = scenes.soup(500, seed=12)
+    mesh = product_mesh(sc)
+    b = api.Bvh.build(mesh, True, 4, 20)
+    doc = json.loads(b.to_json())
+
+    def rewrite(n, depth=0):
+        if n is None:
+            return None
+        bounds = dict(n["Bounds"])
+        if depth % 2:
+            del bounds["Bounds"]                      # Min/Max only
+        else:
+            bounds = {"extra": {"a": [1, {"b": None}], "c": "}"}, "BOUNDS": bounds["Bounds"]}
+        out = {"splitplane": n["SplitPlane"], "EndIndex": n["EndIndex"], "Bounds": bounds,
+               "Note": "x\\\"y", "RightChild": rewrite(n["RightChild"], depth + 1),
+               "startindex": n["StartIndex"], "LeftChild": rewrite(n["LeftChild"], depth + 1)}
+        return out
+
+    text = json.dumps({"Version": [1, 2, {"k": "v"}], "Root": rewrite(doc["Root"])}, indent=1)
+    assert _same(b.export(), api.Bvh.from_json(mesh, text).export())
+
+
 def test_json_errors_are_reported_not_raised_as_crashes(product_lib):
     mesh = product_mesh(scenes.soup(10, seed=1))
     with pytest.raises(api._capi.RtError) as e:
@@ -89,6 +115,22 @@ def test_json_errors_are_reported_not_raised_as_crashes(product_lib):
     assert e.value.status == -4
     with pytest.raises(api._capi.RtError):
         api.Bvh.from_json(mesh, "{}")
+    leaf = {"Bounds": {"Min": [0, 0, 0], "Max": [1, 1, 1]}, "StartIndex": 0, "EndIndex": 9,
+            "LeftChild": None, "RightChild": None, "SplitPlane": [0, 0, 0, 0]}
+    assert api.Bvh.from_json(mesh, json.dumps({"Root": leaf})).export()["is_leaf"].tolist() == [1]
+    for bad in ({"Root": None}, {"Root": 3}, [leaf],
+                {"Root": dict(leaf, LeftChild=leaf)},                       # a single child
+                {"Root": dict(leaf, Bounds={"Min": [0, 0, 0]})},            # no usable bounds
+                {"Root": dict(leaf, Bounds={"Min": [0, 0, "x"], "Max": [1, 1, 1]})},
+                {"Root": dict(leaf, EndIndex=10)},                          # past the triangle array
+                {"Root": dict(leaf, EndIndex=1e12)}):
+        with pytest.raises(api._capi.RtError):
+            api.Bvh.from_json(mesh, json.dumps(bad))
+    for text in (json.dumps({"Root": leaf}) + " x", '{"Root": {"Bounds": }}', '{"Root": {"Bounds" 1}}',
+                 '{"Root": ' + '{"LeftChild": ' * 5000 + 'null' + '}' * 5000 + '}'):
+        with pytest.raises(api._capi.RtError) as e:
+            api.Bvh.from_json(mesh, text)
+        assert e.value.status == -4
 
 
 def test_binary_cache_round_trip(product_lib, tmp_path):
