@@ -293,9 +293,8 @@ def main():
         total_rays, kernel_ms = float(acc["rays"]), acc["kernel_ms"]
 
     if rank == 0:
-        # triangles 48 B + material 4 B each; one 32-B reference-order node and about one 64-B
-        # ordered record per node of the tree
-        scene_mb = (mesh.n_tris * 52 + bvh.n_nodes * 32 + bvh.n_nodes * 64) / 1e6
+        # what the library holds in HBM for the scene: triangle records, both tree views, shading words, tables
+        scene_mb = scene.info()["total_device_bytes"] / 1e6
         value = total_rays / elapsed / 1e6
         # roofline of the traversal kernel: this rank's algorithmic bytes over the
         # time its traversal launches took (HIP events on the launch stream)

@@ -247,8 +247,8 @@ rt_status rt_scene_info_get(const rt_scene *scene, rt_scene_info *out) {
     out->has_light = s.light.found;
     out->node_bytes = s.node_bytes;
     out->tri_bytes = s.tri_bytes;
-    out->total_device_bytes = s.node_bytes + s.tri_bytes + (uint64_t)s.n_tris * 4 +
-                              (uint64_t)(s.n_cam + s.n_light) * 16;
+    out->total_device_bytes = s.node_bytes * (s.d_linked ? 2 : 1) + s.wide_bytes + s.tri_bytes +
+                              (uint64_t)s.n_tris * 16 + (uint64_t)(s.n_cam + s.n_light) * 16;
     return RT_OK;
 }
 

@@ -66,7 +66,10 @@ struct DevScene {
     const f4 *linked;
     int32_t n_top;
     const f4 *tris;
-    const int32_t *tri_mat;     // material id, bit 30 set when the material is "Light"
+    // What shading needs of a triangle, one 16-byte word per array position so
+    // that a path vertex costs one scattered fetch: (N.x, N.y, N.z, bits(m)),
+    // m = material id, bit 30 set when the material is "Light".
+    const f4 *tri_shade;
     const float *kd;            // n_materials * 3
     const float *tri_uv;        // n_tris * 6 or nullptr
     const int32_t *mat_tex;     // n_materials texture slot or -1 (nullptr: none)
@@ -481,8 +484,9 @@ RT_HD v3 random_in_hemisphere(uint64_t stream, uint32_t &ctr, const v3 &normal) 
 
 // trace.go:154-187 getMaterialParameters: Kd, optionally times the nearest
 // texel of map_Kd (texture.go:48-59; no V flip, repeat wrap by uv - floor(uv)).
-RT_HD v3 material_diffuse(const DevScene &s, int32_t tri_pos, float u, float v) {
-    const int32_t mat = s.tri_mat[tri_pos] & (kLightBit - 1);
+// `mat_word` is the w component of the triangle's tri_shade word.
+RT_HD v3 material_diffuse(const DevScene &s, int32_t tri_pos, int32_t mat_word, float u, float v) {
+    const int32_t mat = mat_word & (kLightBit - 1);
     v3 kd{s.kd[3 * mat], s.kd[3 * mat + 1], s.kd[3 * mat + 2]};
     if (s.mat_tex == nullptr || s.tri_uv == nullptr) return kd;
     const int32_t slot = s.mat_tex[mat];

@@ -49,7 +49,7 @@ struct Scene {
     rtc::f4 *d_wide = nullptr;        // ordered-traversal records (fast mode), may be null
     uint32_t fast_root = 0;
     uint64_t wide_bytes = 0;
-    int32_t *d_tri_mat = nullptr;
+    rtc::f4 *d_tri_shade = nullptr;   // per triangle (normal, material word)
     float *d_kd = nullptr;
     float *d_tri_uv = nullptr;
     int32_t *d_mat_tex = nullptr;

@@ -574,7 +574,7 @@ __device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &
         const rt_hit sh = w.hits[in][q];
         const bool reached = sh.t < kF32Max;   // rayCast returned a result
         const bool lit = reached && (sh.t >= dist ||
-                                     (sh.tri_pos >= 0 && (s.tri_mat[sh.tri_pos] & kLightBit) != 0));
+                                     (sh.tri_pos >= 0 && (f2i(s.tri_shade[sh.tri_pos].w) & kLightBit) != 0));
         if (lit) {
             shading.x = shading.x + w.shadow_col[3 * slot + 0];
             shading.y = shading.y + w.shadow_col[3 * slot + 1];
@@ -629,9 +629,9 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     v3 point{0, 0, 0}, normal{0, 0, 1}, diffuse{0, 0, 0};
     if (at_vertex) {
         point = v3{ro.x + rd.x * hit.t, ro.y + rd.y * hit.t, ro.z + rd.z * hit.t};
-        const f4 q0 = s.tris[3 * (size_t)hit.tri_pos];
+        const f4 q0 = s.tri_shade[hit.tri_pos];
         normal = v3{q0.x, q0.y, q0.z};
-        diffuse = material_diffuse(s, hit.tri_pos, hit.u, hit.v);
+        diffuse = material_diffuse(s, hit.tri_pos, f2i(q0.w), hit.u, hit.v);
     }
     const uint64_t stream = at_vertex ? w.rng_stream[id] : 0;
     const uint64_t lbase = light_base(stream);
@@ -870,7 +870,14 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
         }
     }
     if ((st = upload(&sc->d_tris, flat.tris.data(), flat.tris.size() * 4)) != RT_OK) return st;
-    if ((st = upload(&sc->d_tri_mat, flat.tri_mat.data(), flat.tri_mat.size() * 4)) != RT_OK) return st;
+    {
+        std::vector<float> shade((size_t)mesh.n_tris * 4);
+        for (size_t i = 0; i < (size_t)mesh.n_tris; ++i) {
+            std::memcpy(&shade[4 * i], &flat.tris[12 * i], 12);   // the normal leads the triangle record
+            shade[4 * i + 3] = rtc::i2f(flat.tri_mat[i]);
+        }
+        if ((st = upload(&sc->d_tri_shade, shade.data(), shade.size() * 4)) != RT_OK) return st;
+    }
     if ((st = upload(&sc->d_kd, mesh.kd, (size_t)mesh.n_materials * 12)) != RT_OK) return st;
     if (mesh.texcoords)
         if ((st = upload(&sc->d_tri_uv, flat.tri_uv.data(), flat.tri_uv.size() * 4)) != RT_OK) return st;
@@ -958,7 +965,7 @@ void scene_destroy(Scene *sc) {
     workspace_free(*sc);
     for (uint8_t *p : sc->tex_ptrs)
         if (p) (void)hipFree(p);
-    void *ptrs[] = {sc->d_linked, sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_mat, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+    void *ptrs[] = {sc->d_linked, sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_shade, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -972,7 +979,7 @@ static DevScene dev_view(const Scene &sc) {
     d.linked = sc.d_linked;
     d.n_top = sc.n_top;
     d.tris = sc.d_tris;
-    d.tri_mat = sc.d_tri_mat;
+    d.tri_shade = sc.d_tri_shade;
     d.kd = sc.d_kd;
     d.tri_uv = sc.d_tri_uv;
     d.mat_tex = sc.d_tex_ptrs ? sc.d_mat_tex : nullptr;

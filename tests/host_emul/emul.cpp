@@ -101,7 +101,10 @@ void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t
     DevScene s{};
     s.nodes = reinterpret_cast<const f4 *>(nodes);
     s.tris = reinterpret_cast<const f4 *>(tris);
-    s.tri_mat = tri_mat;
+    std::vector<f4> shade((size_t)n_tris);   // (normal, material word) per triangle, as the library builds it
+    for (int32_t i = 0; i < n_tris; ++i)
+        shade[(size_t)i] = f4{tris[12 * (size_t)i], tris[12 * (size_t)i + 1], tris[12 * (size_t)i + 2], i2f(tri_mat[i])};
+    s.tri_shade = shade.data();
     s.kd = kd;
     s.tri_uv = g_tri_uv;
     s.mat_tex = g_mat_tex;
@@ -140,9 +143,9 @@ void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t
                 v3 ro = o, rd = d;
                 for (int k = 0;; ++k) {
                     const v3 point{ro.x + rd.x * h.t, ro.y + rd.y * h.t, ro.z + rd.z * h.t};
-                    const f4 q0 = s.tris[3 * (size_t)h.pos];
+                    const f4 q0 = s.tri_shade[h.pos];
                     const v3 normal{q0.x, q0.y, q0.z};
-                    const v3 diffuse = material_diffuse(s, h.pos, h.u, h.v);
+                    const v3 diffuse = material_diffuse(s, h.pos, f2i(q0.w), h.u, h.v);
                     v3 sh{0, 0, 0};
                     for (int i = 0; i < p.L; ++i) {
                         v3 dn, col; float dist;
@@ -150,7 +153,7 @@ void emul_render(const float *nodes, int32_t n_nodes, const float *tris, int32_t
                             Hit<float> shh;
                             cast(point, dn, dist, shh);
                             const bool reached = shh.t < kF32Max;
-                            const bool lit = reached && (shh.t >= dist || (shh.pos >= 0 && (s.tri_mat[shh.pos] & kLightBit)));
+                            const bool lit = reached && (shh.t >= dist || (shh.pos >= 0 && (f2i(s.tri_shade[shh.pos].w) & kLightBit)));
                             if (lit) sh = v3{sh.x + col.x, sh.y + col.y, sh.z + col.z};
                         }
                     }
