@@ -31,7 +31,7 @@ def _compare(out, ref):
     assert out["stats"]["rays"] == ref["counters"]["rays"]
 
 
-@pytest.mark.parametrize("L,B,spp", [(6, 3, 3), (1, 0, 1), (2, 6, 2), (1, 4, 1)])
+@pytest.mark.parametrize("L,B,spp", [(6, 3, 3), (1, 0, 1), (2, 6, 2), (1, 4, 1), (0, 2, 2), (1, 60, 1)])
 def test_cornell_tile_bit_exact(cornell_pair, oracle, L, B, spp):
     scene, osc = cornell_pair
     d = scenes.make_pass_dict(250, 250, CORNELL_CAM, spp=spp, bounces=B, light_samples=L,
@@ -40,7 +40,11 @@ def test_cornell_tile_bit_exact(cornell_pair, oracle, L, B, spp):
     out = scene.render_tile(api.pass_from_dict(d))
     ref = osc.render_tile(oracle.pass_from_dict(d))
     _compare(out, ref)
-    assert out["rgba"][..., :3].max() > 60
+    if L > 0:
+        assert out["rgba"][..., :3].max() > 60
+    else:
+        # LightSampleRays 0: 0 * (1/0) in trace.go:75-77 makes every lit sample NaN, in both
+        assert np.isnan(out["accum"]).any()
 
 
 def test_batch_shape_does_not_change_the_image(cornell_pair, oracle):
