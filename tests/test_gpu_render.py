@@ -285,3 +285,32 @@ def test_render_calls_on_one_scene_take_turns(cornell_pair):
     assert not errors, errors
     for i in range(2):
         assert np.array_equal(rgba[i].cpu().numpy().reshape(120, 120, 4), alone[i])
+
+
+@pytest.mark.parametrize("variant", ["orthographic", "rotated", "debug_light", "no_gamma"])
+def test_camera_and_settings_variants_bit_exact(cornell_pair, oracle, variant):
+    """The pass fields outside the bundled preset's values: orthographic
+    projection (camera.go:113-121), a camera rotated about all three axes with
+    another projection-plane distance, the forced debug light at its own
+    transform (context.go:257-271), gamma correction off (main.go:158-172) --
+    each on an off-centre, non-square tile of the frame."""
+    scene, osc = cornell_pair
+    cam = dict(CORNELL_CAM)
+    kw = dict(spp=2, bounces=2, light_samples=2, intensity=60.0, seed=7, x_offset=40, y_offset=70,
+              tile_w=90, tile_h=50, task_id=3)
+    if variant == "orthographic":
+        kw["projection"] = 1
+    if variant == "rotated":
+        cam.update(rx=-0.2, ry=0.35, rz=0.1)
+        kw.update(fov=70.0, ppd=2.5)
+    if variant == "no_gamma":
+        kw["gamma_on"] = False
+    d = scenes.make_pass_dict(200, 160, cam, **kw)
+    if variant == "debug_light":
+        d["Settings"]["ForceDebugLight"] = True
+        d["Settings"]["DebugLightSize"] = 0.7
+        d["Settings"]["DebugLightTransform"] = scenes.camera_transform(0.3, 4.0, 1.0, -1.2, 0.2, 0.0)
+    out = scene.render_tile(api.pass_from_dict(d))
+    ref = osc.render_tile(oracle.pass_from_dict(d))
+    _compare(out, ref)
+    assert out["rgba"][..., :3].max() > 20
