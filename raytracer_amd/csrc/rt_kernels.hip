@@ -1362,6 +1362,18 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
         }
         stats->kernel_ms = kms;
         stats->kernel_launches = trace_events.size();
+        if (std::getenv("RT_DIAG") && trace_events.size() >= (size_t)(B + 2)) {
+            // the last batch: queue lengths and launch times per path depth
+            std::vector<uint32_t> counts((size_t)(B + 2));
+            HIP_TRY(hipMemcpy(counts.data(), w.counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (int k = 0; k < B + 2; ++k) {
+                float t = 0;
+                const auto &pr = trace_events[trace_events.size() - (size_t)(B + 2) + (size_t)k];
+                HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+                std::fprintf(stderr, "[rt diag] last batch, queue %d: %u rays in %.3f ms = %.0f Mrays/s\n", k,
+                             counts[(size_t)k], t, t > 0 ? counts[(size_t)k] / t / 1e3 : 0.0);
+            }
+        }
         unsigned long long total = 0;
         HIP_TRY(hipMemcpy(&total, w.ray_total, 8, hipMemcpyDeviceToHost));
         stats->rays = total;
