@@ -14,7 +14,12 @@
 
 namespace rt {
 
-constexpr uint32_t kCursorSlots = 64;   // ring of ray-queue cursors, one per in-flight launch
+// Ring of ray-queue cursors, one per traversal launch, each in a 64-byte line of
+// its own.  A slot is used again 1024 launches later; launches on one stream
+// are ordered anyway, so only that many launches in flight at once on
+// different streams could ever share one.
+constexpr uint32_t kCursorSlots = 1024;
+constexpr uint32_t kCursorStride = 16;  // in 32-bit words
 
 // Per-batch path state of the wavefront path tracer (all device pointers).
 struct PathBuffers {

@@ -892,8 +892,8 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
         sc->fast_root = flat.fast_root;
         sc->wide_bytes = flat.wide.size() * 4;
     }
-    if ((st = upload(&sc->d_cursors, nullptr, kCursorSlots * sizeof(uint32_t))) != RT_OK) return st;
-    HIP_TRY(hipMemset(sc->d_cursors, 0, kCursorSlots * sizeof(uint32_t)));
+    if ((st = upload(&sc->d_cursors, nullptr, (size_t)kCursorSlots * kCursorStride * sizeof(uint32_t))) != RT_OK) return st;
+    HIP_TRY(hipMemset(sc->d_cursors, 0, (size_t)kCursorSlots * kCursorStride * sizeof(uint32_t)));
     HIP_TRY(hipEventCreateWithFlags(&sc->ws_done, hipEventDisableTiming));
 
     // default sample tables (same row counts as the reference's)
@@ -1013,7 +1013,7 @@ static uint32_t trace_grid(const Scene &sc, size_t n) {
 
 static uint32_t *next_cursor(Scene &sc) {
     const uint32_t slot = sc.cursor_next.fetch_add(1) % kCursorSlots;
-    return sc.d_cursors + slot;
+    return sc.d_cursors + (size_t)slot * kCursorStride;
 }
 
 rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,

@@ -335,3 +335,40 @@ def test_tuning_does_not_change_results(soup20k):
                     assert st[key] == base[mode][1][key], (tune, mode, key)
     finally:
         scene.set_tuning(8, 0, 8, 0, 0)
+
+
+def test_trace_calls_from_two_threads_on_two_streams(soup20k):
+    """rt_trace_rays_device is asynchronous and keeps no per-call state in the
+    scene beyond a ray cursor of its own: two host threads launching on two
+    streams at once (many short launches, both modes) get the hits of a call
+    made alone."""
+    import threading
+    import torch
+    _, _, _, scene, _ = soup20k
+    sets = [random_rays(200_000, seed=31), random_rays(150_000, seed=32, extent=1.0)]
+    modes = [api.MODE_STRICT_F32, api.MODE_FAST_F32]
+    alone = [scene.trace_rays(r, mode=m)[0] for r, m in zip(sets, modes)]
+    d_rays = [torch.from_numpy(r.view(np.float32).reshape(-1, 8).copy()).cuda() for r in sets]
+    d_hits = [[torch.zeros((len(r), 4), dtype=torch.float32, device="cuda") for _ in range(40)] for r in sets]
+    streams = [torch.cuda.Stream() for _ in sets]
+    errors = []
+
+    def work(i):
+        try:
+            for k in range(40):
+                scene.trace_rays_device(d_rays[i].data_ptr(), len(sets[i]), d_hits[i][k].data_ptr(),
+                                        mode=modes[i], stream=streams[i].cuda_stream)
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        want = alone[i].view(np.uint32).reshape(-1, 4)
+        for k in (0, 17, 39):
+            assert np.array_equal(d_hits[i][k].cpu().numpy().view(np.uint32), want), (i, k)
