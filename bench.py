@@ -99,10 +99,19 @@ def cpu_baseline(sc, bvh_export, tables, wl, args, tile_list):
     # visit tiles in a stride that spreads over the frame
     order = [tile_list[(i * 37) % len(tile_list)] for i in range(len(tile_list))]
     lock = threading.Lock()
-    state = {"next": 0, "rays": 0, "tiles": 0}
-    deadline = time.perf_counter() + args.cpu_seconds
 
-    def worker():
+    def timed(n_workers, seconds):
+        state = {"next": 0, "rays": 0, "tiles": 0}
+        deadline = time.perf_counter() + seconds
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(state, deadline)) for _ in range(n_workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return state, time.perf_counter() - t0
+
+    def worker(state, deadline):
         while True:
             with lock:
                 if state["next"] >= len(order) or time.perf_counter() > deadline:
@@ -119,18 +128,16 @@ def cpu_baseline(sc, bvh_export, tables, wl, args, tile_list):
                 state["rays"] += out["counters"]["rays"]
                 state["tiles"] += 1
 
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker) for _ in range(n_threads)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
+    state, dt = timed(n_threads, args.cpu_seconds)
+    # the same tiles on ONE thread (the reference runs one wasm instance per worker), a few seconds
+    one, dt1 = timed(1, min(4.0, args.cpu_seconds / 4))
     return {"value": state["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": n_threads,
             "kind": "port",
+            "single_core_value": round(one["rays"] / dt1 / 1e6, 3) if one["rays"] else None,
             "sample": f"{state['tiles']} of {len(tile_list)} tiles of the same frame at 1 spp, "
                       f"{state['rays']} rays in {dt:.1f} s, scalar C restatement of the "
-                      f"reference algorithm, one thread per tile worker"}
+                      f"reference algorithm, one thread per tile worker; single_core_value: "
+                      f"{one['tiles']} tiles, {one['rays']} rays in {dt1:.1f} s on one thread"}
 
 
 def main():
