@@ -45,3 +45,27 @@ def test_version_and_error_text(product_lib):
         assert e.status == -4 and "JSON" in e.message
     else:
         raise AssertionError("expected RtError")
+
+
+def test_plain_c_caller(product_lib, tmp_path):
+    """tests/c_abi/caller.c: a C99 program (-pedantic -Werror) includes both
+    headers, links the library and drives the host-side entry points; the
+    struct sizes it prints equal the ctypes mirror's."""
+    import subprocess
+    from raytracer_amd import _capi
+    lib_dir = os.path.join(ROOT, "raytracer_amd", "lib")
+    exe = str(tmp_path / "caller")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                           "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "caller.c"),
+                           "-L", lib_dir, "-lraytracer_amd", "-Wl,-rpath," + lib_dir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    words = out.stdout.split()
+    sizes = dict(zip(words[0::2], map(int, words[1::2])))
+    from raytracer_amd import api
+    mirror = {"rt_pass": _capi.Pass, "rt_camera": _capi.Camera, "rt_settings": _capi.Settings,
+              "rt_light": _capi.Light, "rt_stats": _capi.Stats, "rt_mesh": _capi.Mesh}
+    for name, cls in mirror.items():
+        assert sizes[name] == C.sizeof(cls), name
+    assert sizes["rt_ray"] == 32 == api.RAY_DTYPE.itemsize and sizes["rt_hit"] == 16 == api.HIT_DTYPE.itemsize
