@@ -9,7 +9,51 @@
 #include "rt_amd.h"
 #include "rt_backend.h"
 
-int main(void) {
+/* Device part (argument "gpu"): the two-triangle scene, rays whose answers are
+ * known by hand.  Triangle 0 lies in z = 0, triangle 1 in z = 1, both facing
+ * +z with the right angle at (0, 0, z) (triangle.go:78-103: one-sided test,
+ * u along v0->v1, v along v0->v2). */
+static int device_part(const rt_mesh *mesh) {
+    rt_bvh *bvh = NULL;
+    rt_scene *scene = NULL;
+    rt_ray rays[4];
+    rt_hit hits[4];
+    rt_stats stats;
+    int mode;
+    if (rt_bvh_build(mesh, 0, 6, 16, &bvh) != RT_OK) return 20;
+    if (rt_scene_create(mesh, bvh, 0, &scene) != RT_OK) {
+        fprintf(stderr, "%s\n", rt_last_error());
+        return 21;
+    }
+    memset(rays, 0, sizeof rays);
+    /* 0: straight down onto triangle 1 (z = 1) at (0.25, 0.5): t = 1, u = 0.25, v = 0.5 */
+    rays[0].origin[0] = 0.25f; rays[0].origin[1] = 0.5f; rays[0].origin[2] = 2.0f;
+    rays[0].dir[2] = -1.0f; rays[0].tmax = 3.4028235e38f;
+    /* 1: the same ray starting between the triangles: reaches triangle 0 at t = 0.5 */
+    rays[1] = rays[0]; rays[1].origin[2] = 0.5f;
+    /* 2: from below, along +z: both triangles are back-facing, nothing is hit */
+    rays[2] = rays[0]; rays[2].origin[2] = -1.0f; rays[2].dir[2] = 1.0f;
+    /* 3: the first ray again, cut short before the triangle */
+    rays[3] = rays[0]; rays[3].tmax = 0.75f;
+    for (mode = RT_MODE_STRICT_F32; mode <= RT_MODE_FAST_F32; ++mode) {
+        memset(hits, 0xff, sizeof hits);
+        if (rt_trace_rays(scene, rays, 4, hits, mode, 0, &stats) != RT_OK) {
+            fprintf(stderr, "%s\n", rt_last_error());
+            return 22;
+        }
+        if (stats.rays != 4) return 23;
+        if (hits[0].tri_pos != 1 || hits[0].t != 1.0f || hits[0].u != 0.25f || hits[0].v != 0.5f) return 24;
+        if (hits[1].tri_pos != 0 || hits[1].t != 0.5f || hits[1].u != 0.25f || hits[1].v != 0.5f) return 25;
+        if (hits[2].tri_pos != -1 || hits[2].t != 3.4028235e38f) return 26;
+        if (hits[3].tri_pos != -1 || hits[3].t != 0.75f) return 27;
+    }
+    if (rt_trace_rays(scene, rays, 4, hits, 99, 0, NULL) != RT_ERR_INVALID) return 28;
+    rt_scene_destroy(scene);
+    rt_bvh_destroy(bvh);
+    return 0;
+}
+
+int main(int argc, char **argv) {
     static const float verts[2 * 9] = {0, 0, 0, 1, 0, 0, 0, 1, 0,     /* z = 0 */
                                        0, 0, 1, 1, 0, 1, 0, 1, 1};    /* z = 1 */
     static const float kd[3] = {0.5f, 0.5f, 0.5f};
@@ -34,6 +78,11 @@ int main(void) {
     if (strstr(json, "\"Root\"") == NULL || strstr(json, "\"SplitPlane\"") == NULL) return 5;
     rt_free(json);
     rt_bvh_destroy(bvh);
+
+    if (argc > 1 && strcmp(argv[1], "gpu") == 0) {
+        int rc = device_part(&mesh);
+        if (rc != 0) return rc;
+    }
 
     /* errors are statuses with a message, never an abort */
     bvh = NULL;

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -47,18 +49,34 @@ def test_version_and_error_text(product_lib):
         raise AssertionError("expected RtError")
 
 
-def test_plain_c_caller(product_lib, tmp_path):
-    """tests/c_abi/caller.c: a C99 program (-pedantic -Werror) includes both
-    headers, links the library and drives the host-side entry points; the
-    struct sizes it prints equal the ctypes mirror's."""
+def _build_c_caller(tmp_path):
     import subprocess
-    from raytracer_amd import _capi
     lib_dir = os.path.join(ROOT, "raytracer_amd", "lib")
     exe = str(tmp_path / "caller")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
                            "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c_abi", "caller.c"),
                            "-L", lib_dir, "-lraytracer_amd", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_on_the_gpu(product_lib, gpu_device, tmp_path):
+    """The same C program with its device part: rt_scene_create and
+    rt_trace_rays from C on hand-computed rays (exact t, u, v; back-face cull;
+    tmax cut), in all three modes."""
+    import subprocess
+    out = subprocess.run([_build_c_caller(tmp_path), "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+def test_plain_c_caller(product_lib, tmp_path):
+    """tests/c_abi/caller.c: a C99 program (-pedantic -Werror) includes both
+    headers, links the library and drives the host-side entry points; the
+    struct sizes it prints equal the ctypes mirror's."""
+    import subprocess
+    from raytracer_amd import _capi
+    exe = _build_c_caller(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     words = out.stdout.split()
