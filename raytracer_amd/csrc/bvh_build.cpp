@@ -18,7 +18,6 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
-#include <thread>
 
 #include "gomath.h"
 #include "rt_internal.h"
@@ -214,9 +213,8 @@ struct Builder {
 
         if (depth < 4 && count > 65536) {
             std::unique_ptr<BNode> left;
-            std::thread th([&] { left = build(start, split - 1, depth + 1); });
-            node->right = build(split, end, depth + 1);
-            th.join();
+            run_together({[&] { node->right = build(split, end, depth + 1); },
+                          [&] { left = build(start, split - 1, depth + 1); }});
             node->left = std::move(left);
         } else {
             node->left = build(start, split - 1, depth + 1);
@@ -282,11 +280,7 @@ rt_status build_bvh(const rt_mesh &mesh, bool use_bvh, int32_t max_leaf, int32_t
     bool will_split = use_bvh && n > max_leaf && 0 < max_depth;
     if (will_split) {
         if (n > 200000) {
-            std::thread t0([&] { b.presort_axis(0); });
-            std::thread t1([&] { b.presort_axis(1); });
-            b.presort_axis(2);
-            t0.join();
-            t1.join();
+            run_together({[&] { b.presort_axis(2); }, [&] { b.presort_axis(0); }, [&] { b.presort_axis(1); }});
         } else {
             for (int a = 0; a < 3; ++a) b.presort_axis(a);
         }

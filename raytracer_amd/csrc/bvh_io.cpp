@@ -189,10 +189,7 @@ static rt_status resort_from_planes(const rt_mesh &mesh, Bvh &b) {
             }
         };
         const int use = (int)std::min<size_t>((size_t)n_threads, level.size());
-        std::vector<std::thread> pool;
-        for (int t = 1; t < use; ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        run_together(std::vector<std::function<void()>>((size_t)use, work));
     }
     return RT_OK;
 }

@@ -3,7 +3,10 @@
 #pragma once
 
 #include <cstdint>
+#include <exception>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -14,6 +17,33 @@ constexpr float kF32Max = 3.40282346638528859811704183484516925440e+38f;
 
 // Sets the calling thread's error text and returns `code` (for `return fail(...)`).
 rt_status fail(rt_status code, const std::string &msg);
+
+// Runs the tasks at the same time, the first on the calling thread and the
+// others on threads of their own, and returns when all have finished; a task's
+// exception (out of memory, typically) is rethrown here instead of ending the
+// process from inside its thread.
+inline void run_together(const std::vector<std::function<void()>> &tasks) {
+    std::vector<std::exception_ptr> errors(tasks.size());
+    auto guarded = [&](size_t i) {
+        try {
+            tasks[i]();
+        } catch (...) {
+            errors[i] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t i = 1; i < tasks.size(); ++i) {
+        try {
+            threads.emplace_back(guarded, i);
+        } catch (...) {          // no thread to be had: run it here
+            guarded(i);
+        }
+    }
+    if (!tasks.empty()) guarded(0);
+    for (std::thread &t : threads) t.join();
+    for (const std::exception_ptr &e : errors)
+        if (e) std::rethrow_exception(e);
+}
 
 // Host copy of the BVH in preorder (BVHNode.Index order, bvh.go:59-67).
 struct Bvh {
