@@ -61,9 +61,9 @@ struct Builder {
     std::vector<Pre> pre;
     std::vector<int32_t> view[3];   // ids sorted by (c[a], index, id), node ranges contiguous
     std::vector<int32_t> arr;       // the reference's triangle array (ids)
-    std::vector<int32_t> tmp;       // partition scratch, indexed by array position
+    std::vector<int32_t> tmp[3];    // partition scratch per axis, indexed by array position
     std::vector<uint8_t> side;      // per id: 1 = goes right
-    std::vector<float> lsz, rsz;    // sweep areas, indexed by array position
+    std::vector<float> lsz[3], rsz[3];   // sweep areas per axis, indexed by array position
 
     Builder(const rt_mesh &m, bool use, int32_t leaf, int32_t depth)
         : mesh(m), use_bvh(use), max_leaf(leaf), max_depth(depth), n(m.n_tris) {}
@@ -116,11 +116,15 @@ struct Builder {
     // GetSplitPlaneSAH: returns the axis (0..2) or -1 when no candidate beat
     // MaxFloat32 (plane stays the zero vector).
     int sah_plane(int32_t start, int32_t end, float plane[4]) {
-        float lowest = kF32Max;
-        int best_axis = -1;
-        plane[0] = plane[1] = plane[2] = plane[3] = 0;
-        for (int a = 0; a < 3; ++a) {
+        // one sweep per axis; the reference keeps ONE running minimum over the
+        // three axes in turn, so an axis only wins with a strictly lower cost
+        // than the axes before it: the per-axis minima (first index reaching
+        // it) compared in axis order give the same choice, and large nodes
+        // sweep their axes at the same time
+        float best_cost[3], best_d[3];
+        auto sweep = [&](int a) {
             const int32_t *ids = view[a].data();
+            float *ls = lsz[a].data(), *rs = rsz[a].data();
             float mn[3], mx[3];
             std::memcpy(mn, pre[(size_t)ids[start]].mn, 12);
             std::memcpy(mx, pre[(size_t)ids[start]].mx, 12);
@@ -130,7 +134,7 @@ struct Builder {
                     mn[k] = (float)gomath::go_min(mn[k], p.mn[k]);
                     mx[k] = (float)gomath::go_max(mx[k], p.mx[k]);
                 }
-                lsz[(size_t)i] = area(mn, mx);
+                ls[(size_t)i] = area(mn, mx);
             }
             std::memcpy(mn, pre[(size_t)ids[end]].mn, 12);
             std::memcpy(mx, pre[(size_t)ids[end]].mx, 12);
@@ -140,34 +144,50 @@ struct Builder {
                     mn[k] = (float)gomath::go_min(mn[k], p.mn[k]);
                     mx[k] = (float)gomath::go_max(mx[k], p.mx[k]);
                 }
-                rsz[(size_t)i] = area(mn, mx);
+                rs[(size_t)i] = area(mn, mx);
             }
             // cost as written in the reference: left area of [start..i] weighted
             // by (i-start), right area of [i+1..end] weighted by (end-i+1)
+            float lowest = kF32Max, d = 0;
             for (int32_t i = start + 1; i < end; ++i) {
-                float cost = lsz[(size_t)i] * (float)(i - start) + rsz[(size_t)i + 1] * (float)(end - i + 1);
+                float cost = ls[(size_t)i] * (float)(i - start) + rs[(size_t)i + 1] * (float)(end - i + 1);
                 if (cost < lowest) {
                     lowest = cost;
-                    best_axis = a;
-                    plane[3] = (pre[(size_t)ids[i]].c[a] + pre[(size_t)ids[i + 1]].c[a]) / 2.0f;
+                    d = (pre[(size_t)ids[i]].c[a] + pre[(size_t)ids[i + 1]].c[a]) / 2.0f;
                 }
             }
-        }
+            best_cost[a] = lowest;
+            best_d[a] = d;
+        };
+        if (end - start + 1 > 65536)
+            run_together({[&] { sweep(0); }, [&] { sweep(1); }, [&] { sweep(2); }});
+        else
+            for (int a = 0; a < 3; ++a) sweep(a);
+        float lowest = kF32Max;
+        int best_axis = -1;
+        plane[0] = plane[1] = plane[2] = plane[3] = 0;
+        for (int a = 0; a < 3; ++a)
+            if (best_cost[a] < lowest) {
+                lowest = best_cost[a];
+                best_axis = a;
+                plane[3] = best_d[a];
+            }
         if (best_axis >= 0) plane[best_axis] = 1;
         return best_axis;
     }
 
     void partition_view(int a, int32_t start, int32_t end, int32_t split) {
         int32_t *ids = view[a].data();
+        int32_t *t = tmp[a].data();
         int32_t l = start, r = split;
         for (int32_t i = start; i <= end; ++i) {
             int32_t id = ids[i];
             if (side[(size_t)id])
-                tmp[(size_t)r++] = id;
+                t[(size_t)r++] = id;
             else
-                tmp[(size_t)l++] = id;
+                t[(size_t)l++] = id;
         }
-        std::memcpy(ids + start, tmp.data() + start, sizeof(int32_t) * (size_t)(end - start + 1));
+        std::memcpy(ids + start, t + start, sizeof(int32_t) * (size_t)(end - start + 1));
     }
 
     std::unique_ptr<BNode> build(int32_t start, int32_t end, int32_t depth) {
@@ -208,8 +228,14 @@ struct Builder {
 
         for (int32_t i = start; i < split; ++i) side[(size_t)arr[(size_t)i]] = 0;
         for (int32_t i = split; i <= end; ++i) side[(size_t)arr[(size_t)i]] = 1;
-        for (int a = 0; a < 3; ++a)
-            if (a != axis) partition_view(a, start, end, split);
+        if (count > 65536 && axis >= 0) {
+            const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            run_together({[&] { partition_view(a1, start, end, split); },
+                          [&] { partition_view(a2, start, end, split); }});
+        } else {
+            for (int a = 0; a < 3; ++a)
+                if (a != axis) partition_view(a, start, end, split);
+        }
 
         if (depth < 4 && count > 65536) {
             std::unique_ptr<BNode> left;
@@ -284,10 +310,12 @@ rt_status build_bvh(const rt_mesh &mesh, bool use_bvh, int32_t max_leaf, int32_t
         } else {
             for (int a = 0; a < 3; ++a) b.presort_axis(a);
         }
-        b.tmp.resize((size_t)n);
         b.side.resize((size_t)n);
-        b.lsz.resize((size_t)n + 1);
-        b.rsz.resize((size_t)n + 1);
+        for (int a = 0; a < 3; ++a) {
+            b.tmp[a].resize((size_t)n);
+            b.lsz[a].resize((size_t)n + 1);
+            b.rsz[a].resize((size_t)n + 1);
+        }
     }
     std::unique_ptr<BNode> root = b.build(0, n - 1, 0);
     out = Bvh();

@@ -20,6 +20,7 @@ def _same(a, b):
 @pytest.mark.parametrize("n,leaf,depth,seed", [
     (1, 6, 16, 1), (2, 1, 8, 2), (3, 1, 8, 3), (7, 6, 16, 4), (34, 6, 16, 5), (500, 2, 40, 6),
     (4096, 6, 16, 7), (4096, 6, 5, 8), (30000, 8, 40, 9), (2000, 0, 12, 10),
+    (140000, 8, 40, 11),      # above the size from which subtrees, axis sweeps and partitions run on threads
 ])
 def test_builder_matches_literal_restatement(product_lib, oracle, n, leaf, depth, seed):
     sc = scenes.soup(n, seed=1000 + seed)
