@@ -19,8 +19,9 @@ namespace {
 // Step 1, small leaves: the reference's leaves hold up to BVHMaxLeafSize
 // triangles; a leaf with more than kFastSplitLeaf is cut in two by array
 // position (the range is sorted along its parent's split axis, bvh.go:73-76, so
-// the halves are spatially separate) under synthetic interior nodes with tight
-// boxes, until every leaf is small: triangle tests are the poorly-vectorised
+// the parts are spatially separate; the cut is chosen by surface area, see
+// best_cut) under synthetic interior nodes with tight boxes, until every leaf
+// is small: triangle tests are the poorly-vectorised
 // part of the traversal.  Array positions, and with them hit ids and
 // tie-breaking, are unchanged.
 //
@@ -67,6 +68,39 @@ struct WideBuilder {
                 }
         }
     }
+    // Where to cut a leaf range of `count` triangles in two: the first cut of the
+    // cheapest tree of cuts by position, when a part of one or two triangles (a
+    // leaf of this view) costs kLeafCost times its box area and every larger part
+    // its own area plus its two parts.  A leaf visit costs several box tests: it
+    // takes the wave through a change of phase at half-empty lanes.
+    static constexpr int32_t kCutSearch = 16;
+    static constexpr float kLeafCost = 4.0f;
+    int32_t best_cut(int32_t start, int32_t count) const {
+        float cost[kCutSearch + 1][kCutSearch + 1];   // [first][length]
+        int32_t cut[kCutSearch + 1][kCutSearch + 1];
+        for (int32_t len = 1; len <= count; ++len)
+            for (int32_t i = 0; i + len <= count; ++i) {
+                float mn[3], mx[3];
+                range_box(start + i, len, mn, mx);
+                const float d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
+                const float a = d0 * d1 + d0 * d2 + d1 * d2;
+                cut[i][len] = len / 2;
+                if (len <= rtc::kFastSplitLeaf) {
+                    cost[i][len] = a * kLeafCost;
+                    continue;
+                }
+                float best = std::numeric_limits<float>::max();
+                for (int32_t k = 1; k < len; ++k) {
+                    const float c = cost[i][k] + cost[i + k][len - k];
+                    if (c < best) {
+                        best = c;
+                        cut[i][len] = k;
+                    }
+                }
+                cost[i][len] = a + best;
+            }
+        return cut[0][count];
+    }
     // step 1 for one leaf range whose box is already known
     int32_t small_leaf(int32_t start, int32_t count, const float mn[3], const float mx[3]) {
         const int32_t id = (int32_t)bin.size();
@@ -78,7 +112,7 @@ struct WideBuilder {
             bin[(size_t)id].count = count;
             return id;
         }
-        const int32_t half = count / 2;
+        const int32_t half = count <= kCutSearch ? best_cut(start, count) : count / 2;
         float lmn[3], lmx[3];
         range_box(start, half, lmn, lmx);
         const int32_t l = small_leaf(start, half, lmn, lmx);
