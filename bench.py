@@ -310,8 +310,12 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.mode == "fast":   # the counters were collected on the ordered kernel
+            # measured per ray on shorter launches of the same workload (a counter pass renders a few
+            # samples per pixel); per launch of THIS run, like `achieved`: x this run's rays per launch
             with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+                per_ray = json.load(f).get(args.workload, {}).get("hbm_bytes_per_ray")
+            if per_ray and acc["launches"]:
+                traffic = round(per_ray * rank_rays / acc["launches"], 1)
         out = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -343,7 +347,7 @@ def main():
                                  "triangle fetches) / traversal-launch time; achieved_reference_order prices "
                                  "the same rays at what the reference's left-first binary walk fetches. A scene below 256 MB is "
                                  "served from L2 / Infinity Cache, so the algorithmic rate can exceed the "
-                                 "HBM peak; traffic = measured fabric bytes per launch of this workload "
+                                 "HBM peak; traffic = measured fabric bytes per ray of this workload x this run's rays per launch "
                                  "(rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/traffic.json). Random 64-byte record gathers top out "
                                  "at 6.5 TB/s on a 10 MB table, 3.8 TB/s on 64 MB and 3.5 TB/s on 1 GB "
                                  "on this GPU (tools/ubench/gather.hip)"},
