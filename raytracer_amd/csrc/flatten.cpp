@@ -17,11 +17,11 @@ namespace {
 // reference's binary one.
 //
 // Step 1, small leaves: the reference's leaves hold up to BVHMaxLeafSize
-// triangles; a leaf with more than kFastSplitLeaf is cut in two by array
+// triangles; a leaf with more than kFastMaxLeaf is cut in two by array
 // position (the range is sorted along its parent's split axis, bvh.go:73-76, so
-// the parts are spatially separate; the cut is chosen by surface area, see
-// best_cut) under synthetic interior nodes with tight boxes, until every leaf
-// is small: triangle tests are the poorly-vectorised
+// the parts are spatially separate; where to cut, and whether to cut a part of
+// three or four triangles at all, is decided by surface area, see best_cut)
+// under synthetic interior nodes with tight boxes, until every leaf is small: triangle tests are the poorly-vectorised
 // part of the traversal.  Array positions, and with them hit ids and
 // tie-breaking, are unchanged.
 //
@@ -68,11 +68,13 @@ struct WideBuilder {
                 }
         }
     }
-    // Where to cut a leaf range of `count` triangles in two: the first cut of the
-    // cheapest tree of cuts by position, when a part of one or two triangles (a
-    // leaf of this view) costs kLeafCost times its box area and every larger part
-    // its own area plus its two parts.  A leaf visit costs several box tests: it
-    // takes the wave through a change of phase at half-empty lanes.
+    // Where to cut a leaf range of `count` triangles in two (0: leave it whole): the
+    // first cut of the cheapest tree of cuts by position, when a leaf of this view
+    // -- at most kFastMaxLeaf triangles -- costs kLeafCost times its box area per
+    // pair of triangles, and every part that is cut its own area plus its two
+    // parts.  A leaf visit costs several box tests: it takes the wave through a
+    // change of phase at half-empty lanes.  Parts of one or two triangles are
+    // never cut.
     static constexpr int32_t kCutSearch = 16;
     static constexpr float kLeafCost = 4.0f;
     int32_t best_cut(int32_t start, int32_t count) const {
@@ -84,20 +86,23 @@ struct WideBuilder {
                 range_box(start + i, len, mn, mx);
                 const float d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
                 const float a = d0 * d1 + d0 * d2 + d1 * d2;
-                cut[i][len] = len / 2;
-                if (len <= rtc::kFastSplitLeaf) {
-                    cost[i][len] = a * kLeafCost;
-                    continue;
-                }
+                const float whole = a * kLeafCost * (float)((len + 1) / 2);
+                cut[i][len] = 0;
+                cost[i][len] = whole;
+                if (len <= rtc::kFastSplitLeaf) continue;
                 float best = std::numeric_limits<float>::max();
+                int32_t at = len / 2;
                 for (int32_t k = 1; k < len; ++k) {
                     const float c = cost[i][k] + cost[i + k][len - k];
                     if (c < best) {
                         best = c;
-                        cut[i][len] = k;
+                        at = k;
                     }
                 }
-                cost[i][len] = a + best;
+                if (len > rtc::kFastMaxLeaf || a + best <= whole) {
+                    cost[i][len] = a + best;
+                    cut[i][len] = at;
+                }
             }
         return cut[0][count];
     }
@@ -107,12 +112,12 @@ struct WideBuilder {
         bin.emplace_back();
         std::memcpy(bin[(size_t)id].mn, mn, 12);
         std::memcpy(bin[(size_t)id].mx, mx, 12);
-        if (count <= rtc::kFastSplitLeaf) {
+        const int32_t half = count <= rtc::kFastSplitLeaf ? 0 : (count <= kCutSearch ? best_cut(start, count) : count / 2);
+        if (half == 0) {
             bin[(size_t)id].start = start;
             bin[(size_t)id].count = count;
             return id;
         }
-        const int32_t half = count <= kCutSearch ? best_cut(start, count) : count / 2;
         float lmn[3], lmx[3];
         range_box(start, half, lmn, lmx);
         const int32_t l = small_leaf(start, half, lmn, lmx);

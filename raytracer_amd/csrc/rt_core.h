@@ -96,7 +96,8 @@ struct DevScene {
 constexpr int32_t kLightBit = 1 << 30;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefDone = 0xFFFFFFFFu;   // empty-stack marker (count 127, start 2^24-1 is never built)
-constexpr int32_t kFastSplitLeaf = 2;   // larger leaves are cut in two for the ordered traversal
+constexpr int32_t kFastSplitLeaf = 2;   // ordered view: leaf ranges up to this size are never cut (one leaf step tests two triangles)
+constexpr int32_t kFastMaxLeaf = 4;     // ordered view: larger leaf ranges are always cut; between the two the builder weighs the cut
 constexpr int32_t kWideFloats = 16;     // one ordered-traversal record: frame + 4 quantised child boxes + 4 refs = 64 bytes
 constexpr int32_t kFastStackEntries = 96;   // per-ray stack of the ordered traversal
 constexpr int32_t kFastMaxTris = (1 << 24) - 2;
