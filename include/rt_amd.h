@@ -112,8 +112,8 @@ rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float
                      int32_t *tri_material);
 
 /* The second flat view used by RT_MODE_FAST_F32: a 4-wide tree collapsed from
- * the binary one (leaves of more than two triangles cut in two by array
- * position first), one 64-byte record of 16 dwords per interior node:
+ * the binary one (leaves of more than four triangles, and smaller ones where
+ * it pays, cut in two by array position first), one 64-byte record of 16 dwords per interior node:
  *   [0..2]  origin of the record's frame, [3..5] step per axis (extent / 255, nudged up),
  *   [6..8]  lower planes x, y, z -- child c's 8-bit offset in byte c,
  *   [9..11] upper planes x, y, z likewise (a plane is fma(offset, step, origin);
