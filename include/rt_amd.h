@@ -147,9 +147,12 @@ typedef struct rt_scene_info {
     uint64_t node_bytes, tri_bytes, total_device_bytes;
 } rt_scene_info;
 
-/* context.go:172-226 on the host, no device needed: the area light of a mesh
- * whose triangles are visited in the BVH's sorted order (bvh may be NULL for
- * input order). */
+/* context.go:172-226 on the host, no device needed: the area light of a mesh.
+ * The reference finds it inside RenderContext.Initialize (context.go:180),
+ * before buildBVH / loadBVH sort the triangles (main.go:65-90), so the
+ * triangles are visited in input (OBJ) order and the last "Light" triangle in
+ * that order sets normal and size.  `bvh` is ignored (kept for binary
+ * compatibility; pass NULL). */
 rt_status rt_mesh_light(const rt_mesh *mesh, const rt_bvh *bvh, rt_light *out);
 
 /* Copies mesh + tree to device `device` (host memory stays the caller's). */
@@ -181,6 +184,15 @@ rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_
  * the size of its device workspace, about 370 bytes per sample at 4 bounces
  * and 1 light sample); default 67108864. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
+/* Upper bound in bytes on the device memory the tile renderer's workspace may
+ * take on this scene (0 = none, the default).  A batch whose workspace would
+ * be larger is halved, like one that does not fit free device memory; results
+ * do not depend on the batch shape.  For GPUs shared with other work. */
+rt_status rt_scene_set_workspace_limit(rt_scene *scene, uint64_t max_bytes);
+/* Bytes of workspace one camera sample in flight takes at these settings
+ * (two ray queues of LightSampleRays+1 rays and hits, per-vertex terms for
+ * BounceLimit+1 vertices, per-path words). */
+uint64_t rt_workspace_bytes_per_path(int32_t light_sample_rays, int32_t bounce_limit);
 /* Launch parameters of the traversal kernels, for experiments: entries of the
  * per-lane stack kept in LDS (8, 12, 16 or 24; deeper entries spill), the
  * active-lane count below which a wave refills its idle lanes (1..64),

@@ -773,10 +773,12 @@ void orc_scene_light(const orc_scene *s, orc_light *out)
     float normal[3] = {0, 0, 0}, up[3] = {0, 0, 0}, shortest[3] = {0, 0, 0}, middle[3] = {0, 0, 0};
     int found = 0;
     memset(out, 0, sizeof *out);
-    /* iterates context.Triangles in its current order; only the LAST light
-     * triangle's normal and edges survive */
+    /* runs inside RenderContext.Initialize (context.go:180), before buildBVH /
+     * loadBVH sort the array (main.go:65-90): context.Triangles is still in
+     * OBJ order here, so the walk is over the input order whatever tree was
+     * installed since; only the LAST light triangle's normal and edges survive */
     for (int32_t i = 0; i < s->n; ++i) {
-        const OTriangle *t = s->tris[i];
+        const OTriangle *t = &s->store[i];
         if (!t->is_light) continue;
         found = 1;
         memcpy(normal, t->normal, 12);

@@ -95,6 +95,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_int32)]),
     "rt_scene_set_texture": (C.c_int32, [vp, C.c_int32, vp, C.c_int32, C.c_int32]),
     "rt_scene_set_max_paths": (C.c_int32, [vp, C.c_uint64]),
+    "rt_scene_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
+    "rt_workspace_bytes_per_path": (C.c_uint64, [C.c_int32, C.c_int32]),
     "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_scene_set_counters": (C.c_int32, [vp, C.c_int32]),
     "rt_scene_destroy": (None, [vp]),

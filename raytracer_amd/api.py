@@ -153,6 +153,10 @@ class Bvh:
             self._h = None
 
 
+def workspace_bytes_per_path(light_sample_rays, bounce_limit):
+    return int(lib().rt_workspace_bytes_per_path(light_sample_rays, bounce_limit))
+
+
 def default_sample_table(n, seed):
     out = np.zeros((n, 2), np.float64)
     check(lib().rt_default_sample_table(n, seed, _ptr(out)))
@@ -226,6 +230,10 @@ class Scene:
 
     def set_max_paths(self, n):
         check(lib().rt_scene_set_max_paths(self._h, n))
+
+    def set_workspace_limit(self, max_bytes):
+        """Bound on the device bytes of the tile renderer's workspace (0 = none)."""
+        check(lib().rt_scene_set_workspace_limit(self._h, int(max_bytes)))
 
     def set_tuning(self, stack_entries=8, refill_below=0, blocks_per_cu=8, descend_min=0, leaf_min=0):
         """0 for a lane count = the kernel's own default."""

@@ -476,18 +476,72 @@ rt_status bvh_load(const rt_mesh &mesh, const char *path, Bvh &out) {
         std::fclose(f);
         return fail(RT_ERR_INVALID, "cached BVH was built for a different triangle count");
     }
+    // Nothing is allocated from a header field before it is checked against the
+    // file's real size: a binary tree over n triangles has at most 2n - 1 nodes
+    // (one for an empty mesh), and the arrays that follow the header have a
+    // fixed size per node and per triangle.
+    if (ok) {
+        const uint64_t nn64 = (uint64_t)h.n_nodes, nt64 = (uint64_t)h.n_tris;
+        const uint64_t expect = sizeof(FileHeader) + nn64 * (4 * 4 + 3 * 4 + 3 * 4 + 4 * 4) + nt64 * 4;
+        long size = -1;
+        if (std::fseek(f, 0, SEEK_END) == 0) size = std::ftell(f);
+        ok = size >= 0 && (uint64_t)size == expect && nn64 >= 1 && nn64 <= 2 * std::max<uint64_t>(nt64, 1) &&
+             std::fseek(f, (long)sizeof(FileHeader), SEEK_SET) == 0;
+    }
     const size_t nn = ok ? (size_t)h.n_nodes : 0;
     ok = ok && read_vec_file(f, out.is_leaf, nn) && read_vec_file(f, out.start, nn) &&
          read_vec_file(f, out.end, nn) && read_vec_file(f, out.depth, nn) &&
          read_vec_file(f, out.bmin, nn * 3) && read_vec_file(f, out.bmax, nn * 3) &&
          read_vec_file(f, out.split, nn * 4) && read_vec_file(f, out.order, (size_t)h.n_tris);
     std::fclose(f);
-    if (!ok) return fail(RT_ERR_PARSE, std::string("not a BVH cache file: ") + path);
+    if (!ok) return fail(RT_ERR_PARSE, std::string("not a BVH cache file (bad header, or its size does not match its node and triangle counts): ") + path);
     out.n_tris = h.n_tris;
     out.n_nodes = h.n_nodes;
-    out.max_depth = h.max_depth;
-    for (int32_t id : out.order)
-        if (id < 0 || id >= h.n_tris) return fail(RT_ERR_PARSE, "BVH cache holds an invalid triangle id");
+    // the order must be a permutation of the triangle ids
+    std::vector<uint8_t> seen((size_t)h.n_tris, 0);
+    for (int32_t id : out.order) {
+        if (id < 0 || id >= h.n_tris || seen[(size_t)id])
+            return fail(RT_ERR_PARSE, "BVH cache holds an invalid triangle order");
+        seen[(size_t)id] = 1;
+    }
+    // Topology is re-derived from the preorder leaf flags, as the JSON reader
+    // does: depth and max_depth are recomputed (the stored ones are not
+    // trusted), the flags must describe exactly one complete binary tree, every
+    // node's range must lie inside the triangle array, and an interior node's
+    // range must be the concatenation of its children's.
+    out.max_depth = 0;
+    std::vector<std::pair<int32_t, int32_t>> open_nodes;   // (interior node, children seen so far)
+    for (int32_t i = 0; i < h.n_nodes; ++i) {
+        if (i > 0 && open_nodes.empty()) return fail(RT_ERR_PARSE, "BVH cache: nodes after the end of the tree");
+        const int32_t depth = (int32_t)open_nodes.size();
+        const int32_t s = out.start[(size_t)i], e = out.end[(size_t)i];
+        const bool empty_ok = h.n_tris == 0 && i == 0;
+        if (!empty_ok && (s < 0 || e < s || e >= h.n_tris))
+            return fail(RT_ERR_PARSE, "BVH cache: node " + std::to_string(i) + " has a triangle range outside the array");
+        if (!open_nodes.empty()) {
+            const int32_t parent = open_nodes.back().first;
+            const bool first = open_nodes.back().second == 0;
+            if (first ? s != out.start[(size_t)parent] : e != out.end[(size_t)parent])
+                return fail(RT_ERR_PARSE, "BVH cache: node " + std::to_string(i) + " does not continue its parent's range");
+            if (!first) {
+                // the right child starts where the left one ended
+                int32_t left = parent + 1;
+                if (s != out.end[(size_t)left] + 1)
+                    return fail(RT_ERR_PARSE, "BVH cache: children of node " + std::to_string(parent) + " do not tile its range");
+            }
+            open_nodes.back().second++;
+        }
+        out.depth[(size_t)i] = depth;
+        out.max_depth = std::max(out.max_depth, depth);
+        if (out.is_leaf[(size_t)i] != 0 && out.is_leaf[(size_t)i] != 1)
+            return fail(RT_ERR_PARSE, "BVH cache: bad leaf flag");
+        if (!out.is_leaf[(size_t)i]) {
+            open_nodes.emplace_back(i, 0);
+        } else {
+            while (!open_nodes.empty() && open_nodes.back().second == 2) open_nodes.pop_back();
+        }
+    }
+    if (!open_nodes.empty()) return fail(RT_ERR_PARSE, "BVH cache: the tree is truncated");
     return RT_OK;
 }
 

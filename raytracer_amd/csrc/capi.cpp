@@ -170,9 +170,8 @@ rt_status rt_mesh_light(const rt_mesh *mesh, const rt_bvh *bvh, rt_light *out) {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     rt_status st = rt::check_mesh(mesh);
     if (st != RT_OK) return st;
-    if (bvh && bvh->bvh.n_tris != mesh->n_tris)
-        return fail(RT_ERR_INVALID, "BVH was built for a different triangle count");
-    rt::find_light(*mesh, bvh ? bvh->bvh.order : std::vector<int32_t>(), *out);
+    (void)bvh;   // the light does not depend on the tree: see the header
+    rt::find_light(*mesh, *out);
     return RT_OK;
     RT_GUARD_END
 }
@@ -217,6 +216,16 @@ rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
         return fail(RT_ERR_INVALID, "max_paths must be within [64, 2^28]");
     scene->impl->max_paths_in_flight = (size_t)max_paths;
     return RT_OK;
+}
+
+rt_status rt_scene_set_workspace_limit(rt_scene *scene, uint64_t max_bytes) {
+    if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
+    scene->impl->ws_byte_limit = (size_t)max_bytes;
+    return RT_OK;
+}
+
+uint64_t rt_workspace_bytes_per_path(int32_t light_sample_rays, int32_t bounce_limit) {
+    return (uint64_t)rt::workspace_bytes_per_path(light_sample_rays, bounce_limit & 0xff);
 }
 
 rt_status rt_scene_create(const rt_mesh *mesh, const rt_bvh *bvh, int32_t device, rt_scene **out) {

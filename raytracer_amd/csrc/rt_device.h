@@ -21,24 +21,39 @@ namespace rt {
 constexpr uint32_t kCursorSlots = 1024;
 constexpr uint32_t kCursorStride = 16;  // in 32-bit words
 
-// Per-batch path state of the wavefront path tracer (all device pointers).
+// Per-path word, read and written once per path vertex as one 16-byte access.
+//   stream_lo/hi  counter-RNG stream key of the camera sample
+//   packed        bits 0-1 state, bits 2-10 number of shading terms (0..256),
+//                 bits 11-31 RNG draws taken so far (at most 256 x 64 x 3)
+//   bounce_q      slot of the path's current ray in the ray queue being traced
+struct alignas(16) PathHead {
+    uint32_t stream_lo, stream_hi, packed, bounce_q;
+};
+struct alignas(8) Pair32 {
+    float x, y;
+};
+
+// Per-batch path state of the wavefront path tracer (all device pointers into
+// ONE block of device memory, see ws_layout).
 struct PathBuffers {
     rt_ray *rays[2];
     rt_hit *hits[2];
     uint32_t *counts;          // queue lengths: [0] primaries, [k+1] rays emitted at vertex k
-    uint8_t *state;
-    uint8_t *n_terms;
-    uint32_t *rng_ctr;
-    uint64_t *rng_stream;      // per path: counter-RNG stream key
-    int32_t *bounce_q;
-    int32_t *shadow_q;         // P*L
-    float *shadow_dist;        // P*L: length of the shadow ray in that slot
-    float *shadow_col;         // P*L*3
-    float *shading_terms;      // (B+1)*P*3, vertex-major
-    float *brdf_terms;         // (B+1)*P*3
-    float *radiance;           // P*3, [sample][pixel]
+    PathHead *head;            // P
+    // L*P, [i*P + path]: what light sample i adds to the vertex's shading when
+    // its shadow ray reaches the light (xyz), and that ray's slot in the queue
+    // (w, as bits; -1: no ray was cast)
+    rtc::f4 *slots;
+    // (B+1)*P each, [k*P + path], written at vertex k: terms_a = (shading term of
+    // vertex k-1, x of the BRDF term of vertex k), terms_b = its y and z.  The
+    // BRDF term of a path's last vertex is zero in the reference whichever way the
+    // path ends (trace.go:81-84, 92-96) and is not stored.
+    rtc::f4 *terms_a;
+    Pair32 *terms_b;
+    float *radiance;           // 3 planes of P floats (r, g, b), each [sample][pixel]
     unsigned long long *ray_total;
     unsigned long long *trav_counters;   // 8 x u64, filled when the scene counts traversal work
+    uint32_t *cursor;          // ray hand-out cursor of the traversal launches (fixed-block calls only)
 };
 
 struct Scene {
@@ -81,7 +96,9 @@ struct Scene {
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;
     PathBuffers ws{};
-    std::vector<void *> ws_allocs;
+    void *ws_block = nullptr;     // the one allocation the path buffers are carved from
+    size_t ws_block_bytes = 0;
+    size_t ws_byte_limit = 0;     // 0: none; a batch whose workspace would be larger is halved
     rtc::TileDesc *d_tiles = nullptr;   // tile table of a multi-tile call
     size_t tile_cap = 0;
     // The workspace is shared by every render call on this scene: calls take
@@ -98,13 +115,15 @@ void scene_destroy(Scene *sc);
 
 rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,
                        rt_hit *d_hits, int mode, unsigned long long *d_counters,
-                       hipStream_t stream);
+                       hipStream_t stream, uint32_t *d_cursor = nullptr);
 rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits, int mode,
                           bool want_counters, rt_stats *stats);
 rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
                             int32_t sample_begin, int32_t sample_count, bool incremental,
                             bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
                             hipStream_t stream);
+// Bytes of path workspace one camera sample in flight takes at these settings.
+size_t workspace_bytes_per_path(int light_samples, int bounce_limit);
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
                            uint8_t *rgba, rt_stats *stats);
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,

@@ -81,8 +81,9 @@ struct TriRecord {
 };
 void make_tri_record(const float v[9], TriRecord &out);
 
-// context.go:172-226 over triangles in sorted-array order.
-void find_light(const rt_mesh &mesh, const std::vector<int32_t> &order, rt_light &out);
+// context.go:172-226 over the triangles in input order (the reference runs it
+// before any BVH sort).
+void find_light(const rt_mesh &mesh, rt_light &out);
 
 // camera.go:43-85
 void camera_setup(const rt_camera &cam, int32_t total_w, int32_t total_h, float top_left[3],

@@ -532,7 +532,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 // ---------------------------------------------------------------------------
 // Path-tracing wavefront kernels
 // ---------------------------------------------------------------------------
-enum : uint8_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
+enum : uint32_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
+
+__device__ __forceinline__ uint32_t pack_head(uint32_t state, uint32_t n_terms, uint32_t ctr) {
+    return state | (n_terms << 2) | (ctr << 11);
+}
+__device__ __forceinline__ uint32_t head_state(uint32_t packed) { return packed & 3u; }
+__device__ __forceinline__ uint32_t head_terms(uint32_t packed) { return (packed >> 2) & 0x1FFu; }
+__device__ __forceinline__ uint32_t head_ctr(uint32_t packed) { return packed >> 11; }
 
 struct Batch {
     uint32_t P;                // paths in this batch = n_pix * n_samp
@@ -554,31 +561,32 @@ k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
     f4 *rp = reinterpret_cast<f4 *>(w.rays[0] + id);
     rp[0] = f4{o.x, o.y, o.z, kF32Max};
     rp[1] = f4{d.x, d.y, d.z, 0.0f};
-    w.state[id] = kActive;
-    w.n_terms[id] = 0;
-    w.rng_ctr[id] = 0;
-    w.rng_stream[id] = rng_stream(ctx.rng_seed, ctx.path_index);
+    const uint64_t stream = rng_stream(ctx.rng_seed, ctx.path_index);
+    // the primary ray of path `id` sits in slot `id` of queue 0
+    w.head[id] = PathHead{(uint32_t)stream, (uint32_t)(stream >> 32), pack_head(kActive, 0, 0), id};
 }
 
 // Sum of the shadow samples that reached the light, scaled and clamped
 // (trace.go:63-77).  `in` is the queue the shadow rays of the previous vertex
-// were traced in.
+// were traced in.  The reference's test is "T >= lightDistance || the hit
+// triangle is the light" on a cast that started with tmin = lightDistance
+// (trace.go:59-63): a triangle is only ever accepted below the current tmin, so
+// T >= lightDistance holds exactly when no triangle was accepted, and the ray's
+// length need not be kept.
 __device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &p,
-                                           const PathBuffers &w, int in, uint32_t id) {
+                                           const PathBuffers &w, int in, uint32_t id, size_t P) {
     v3 shading{0, 0, 0};
     for (int i = 0; i < p.L; ++i) {
-        const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
-        const int32_t q = w.shadow_q[slot];
+        const f4 slot = w.slots[(size_t)i * P + id];
+        const int32_t q = f2i(slot.w);
         if (q < 0) continue;
-        const float dist = w.shadow_dist[slot];   // the shadow ray's tmax, kept here to spare a gather
         const rt_hit sh = w.hits[in][q];
         const bool reached = sh.t < kF32Max;   // rayCast returned a result
-        const bool lit = reached && (sh.t >= dist ||
-                                     (sh.tri_pos >= 0 && (f2i(s.tri_shade[sh.tri_pos].w) & kLightBit) != 0));
+        const bool lit = reached && (sh.tri_pos < 0 || (f2i(s.tri_shade[sh.tri_pos].w) & kLightBit) != 0);
         if (lit) {
-            shading.x = shading.x + w.shadow_col[3 * slot + 0];
-            shading.y = shading.y + w.shadow_col[3 * slot + 1];
-            shading.z = shading.z + w.shadow_col[3 * slot + 2];
+            shading.x = shading.x + slot.x;
+            shading.y = shading.y + slot.y;
+            shading.z = shading.z + slot.z;
         }
     }
     const float invl = 1 / (float)p.L;
@@ -586,39 +594,31 @@ __device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &
               gomath::clamp01(shading.z * invl)};
 }
 
-__device__ __forceinline__ void store3(float *base, size_t i, const v3 &v) {
-    base[3 * i + 0] = v.x;
-    base[3 * i + 1] = v.y;
-    base[3 * i + 2] = v.z;
-}
-
 // Path vertex k.  Reads queue (k & 1), writes queue ((k+1) & 1).
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = id < b.P && w.state[id] == kActive;
+    const size_t P = b.P;
+    PathHead hd{0, 0, 0, 0};
+    if (id < b.P) hd = w.head[id];
+    const bool live = id < b.P && head_state(hd.packed) == kActive;
     const int in = k & 1, out = in ^ 1;
     uint32_t *out_count = w.counts + k + 1;
-    const size_t P = b.P;
 
     bool at_vertex = false;
     rt_hit hit{};
-    v3 ro{0, 0, 0}, rd{0, 0, 0};
+    v3 ro{0, 0, 0}, rd{0, 0, 0}, prev_shading{0, 0, 0};
+    uint32_t ctr = head_ctr(hd.packed);
     if (live) {
-        uint32_t q = id;
-        if (k > 0) {
-            const v3 sh = fold_shadows(s, p, w, in, id);
-            store3(w.shading_terms, (size_t)(k - 1) * P + id, sh);
-            q = (uint32_t)w.bounce_q[id];
-        }
-        hit = w.hits[in][q];
+        if (k > 0) prev_shading = fold_shadows(s, p, w, in, id, P);
+        hit = w.hits[in][hd.bounce_q];
         if (!(hit.t < kF32Max)) {
-            // primary miss: Trace returns the background; bounce miss: BRDF term 0
-            if (k > 0) store3(w.brdf_terms, (size_t)(k - 1) * P + id, v3{0, 0, 0});
-            w.n_terms[id] = (uint8_t)k;
-            w.state[id] = kComplete;
+            // primary miss: Trace returns the background; bounce miss: the path ends
+            // with k terms, the last vertex's shading is what was just folded
+            w.terms_a[(size_t)k * P + id] = f4{prev_shading.x, prev_shading.y, prev_shading.z, 0.0f};
+            reinterpret_cast<uint2 *>(w.head + id)[1] = make_uint2(pack_head(kComplete, (uint32_t)k, ctr), 0u);
         } else {
-            const f4 *rp = reinterpret_cast<const f4 *>(w.rays[in] + q);
+            const f4 *rp = reinterpret_cast<const f4 *>(w.rays[in] + hd.bounce_q);
             const f4 a = rp[0], c = rp[1];
             ro = v3{a.x, a.y, a.z};
             rd = v3{c.x, c.y, c.z};
@@ -633,7 +633,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         normal = v3{q0.x, q0.y, q0.z};
         diffuse = material_diffuse(s, hit.tri_pos, f2i(q0.w), hit.u, hit.v);
     }
-    const uint64_t stream = at_vertex ? w.rng_stream[id] : 0;
+    const uint64_t stream = (uint64_t)hd.stream_lo | ((uint64_t)hd.stream_hi << 32);
     const uint64_t lbase = light_base(stream);
 
     // shadow rays of this vertex (the loop is uniform over the wave: L is a pass constant)
@@ -646,17 +646,12 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
                                     lbase + (uint64_t)k * (uint64_t)p.L + (uint64_t)i, dn, dist, col);
         const uint32_t q = block_append(out_count, cast, i);
         if (at_vertex) {
-            const size_t slot = (size_t)id * (size_t)p.L + (size_t)i;
             if (cast) {
                 f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + q);
                 rp[0] = f4{point.x, point.y, point.z, dist};
                 rp[1] = f4{dn.x, dn.y, dn.z, 0.0f};
-                w.shadow_q[slot] = (int32_t)q;
-                w.shadow_dist[slot] = dist;
-                store3(w.shadow_col, slot, col);
-            } else {
-                w.shadow_q[slot] = -1;
             }
+            w.slots[(size_t)i * P + id] = f4{col.x, col.y, col.z, i2f(cast ? (int32_t)q : -1)};
         }
     }
 
@@ -665,13 +660,10 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     v3 sample{0, 0, 0};
     if (at_vertex) {
         if (k >= p.B) {
-            store3(w.brdf_terms, (size_t)k * P + id, v3{0, 0, 0});
-            w.n_terms[id] = (uint8_t)(k + 1);
-            w.state[id] = kLastVertex;
+            w.terms_a[(size_t)k * P + id] = f4{prev_shading.x, prev_shading.y, prev_shading.z, 0.0f};
+            reinterpret_cast<uint2 *>(w.head + id)[1] = make_uint2(pack_head(kLastVertex, (uint32_t)k + 1, ctr), 0u);
         } else {
-            uint32_t ctr = w.rng_ctr[id];
             sample = normalize(random_in_hemisphere(stream, ctr, normal));
-            w.rng_ctr[id] = ctr;
             bounce = true;
         }
     }
@@ -680,41 +672,56 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + bq);
         rp[0] = f4{point.x, point.y, point.z, kF32Max};
         rp[1] = f4{sample.x, sample.y, sample.z, 0.0f};
-        w.bounce_q[id] = (int32_t)bq;
         // the direction the path arrived with is the traced ray's own (trace.go:95 currentRay)
         const float f = brdf_factor(rd, sample, normal);
-        // provisional: zeroed by the next vertex if the bounce ray hits nothing
-        store3(w.brdf_terms, (size_t)k * P + id, v3{diffuse.x * f, diffuse.y * f, diffuse.z * f});
+        // the term counts only if the bounce ray hits something: a path whose bounce
+        // misses ends with this vertex as its last, whose BRDF term is zero
+        w.terms_a[(size_t)k * P + id] = f4{prev_shading.x, prev_shading.y, prev_shading.z, diffuse.x * f};
+        w.terms_b[(size_t)k * P + id] = Pair32{diffuse.y * f, diffuse.z * f};
+        reinterpret_cast<uint2 *>(w.head + id)[1] = make_uint2(pack_head(kActive, 0, ctr), bq);
     }
 }
 
-// Last vertex's shadows, then E = shading[0] + brdf[0] folded back to front.
+// Last vertex's shadows, then E = shading[0] + brdf[0] folded back to front
+// (trace.go:114-118): x = 0 for the last vertex, x = brdf[t] * (shading[t+1] + x)
+// going down, E = shading[0] + x.
 __global__ void __launch_bounds__(256)
 k_finish(DevScene s, PassParams p, Batch b, PathBuffers w, int last_queue) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= b.P) return;
     const size_t P = b.P;
-    uint8_t st = w.state[id];
-    const int n = w.n_terms[id];
-    if (st == kLastVertex) {
-        const v3 sh = fold_shadows(s, p, w, last_queue, id);
-        store3(w.shading_terms, (size_t)(n - 1) * P + id, sh);
-    }
+    const PathHead hd = w.head[id];
+    const uint32_t st = head_state(hd.packed);
+    const int n = (int)head_terms(hd.packed);
     v3 rgb{0.0f / 255.0f, 0.0f / 255.0f, 0.0f / 255.0f};
     if (n > 0) {
-        size_t i = (size_t)(n - 1) * P + id;
-        v3 x{w.brdf_terms[3 * i], w.brdf_terms[3 * i + 1], w.brdf_terms[3 * i + 2]};
-        for (int t = n - 2; t >= 0; --t) {
-            const size_t hi = (size_t)(t + 1) * P + id, lo = (size_t)t * P + id;
-            const v3 sn{w.shading_terms[3 * hi], w.shading_terms[3 * hi + 1], w.shading_terms[3 * hi + 2]};
-            const v3 bt{w.brdf_terms[3 * lo], w.brdf_terms[3 * lo + 1], w.brdf_terms[3 * lo + 2]};
-            x = v3{bt.x * (sn.x + x.x), bt.y * (sn.y + x.y), bt.z * (sn.z + x.z)};
+        // shading term of the last vertex: its shadow rays were traced last, or
+        // (bounce missed) the vertex after it already folded and stored them
+        v3 s_hi;
+        if (st == kLastVertex) {
+            s_hi = fold_shadows(s, p, w, last_queue, id, P);
+        } else {
+            const f4 a = w.terms_a[(size_t)n * P + id];
+            s_hi = v3{a.x, a.y, a.z};
         }
-        rgb = v3{w.shading_terms[3 * (size_t)id] + x.x, w.shading_terms[3 * (size_t)id + 1] + x.y,
-                 w.shading_terms[3 * (size_t)id + 2] + x.z};
+        v3 x{0.0f, 0.0f, 0.0f};
+        v3 s_pending{0, 0, 0};                       // shading[t] while the loop works on t
+        if (n > 1) {
+            const f4 a = w.terms_a[(size_t)(n - 1) * P + id];
+            s_pending = v3{a.x, a.y, a.z};
+        }
+        for (int t = n - 2; t >= 0; --t) {
+            const f4 a = w.terms_a[(size_t)t * P + id];   // (shading[t-1], brdf[t].x)
+            const Pair32 yz = w.terms_b[(size_t)t * P + id];
+            x = v3{a.w * (s_hi.x + x.x), yz.x * (s_hi.y + x.y), yz.y * (s_hi.z + x.z)};
+            s_hi = s_pending;
+            s_pending = v3{a.x, a.y, a.z};
+        }
+        rgb = v3{s_hi.x + x.x, s_hi.y + x.y, s_hi.z + x.z};
     }
-    store3(w.radiance, id, rgb);
-    w.state[id] = kDone;
+    w.radiance[id] = rgb.x;
+    w.radiance[P + id] = rgb.y;
+    w.radiance[2 * P + id] = rgb.z;
 }
 
 // pixelColor += rayColor, samples in order (main.go:137-151)
@@ -723,12 +730,13 @@ k_accumulate(Batch b, const float *__restrict__ radiance, float *__restrict__ ac
     const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
     if (pl >= b.n_pix) return;
     const size_t pix = (size_t)b.pix0 + pl;
+    const size_t P = b.P;
     float r = accum[3 * pix], g = accum[3 * pix + 1], bl = accum[3 * pix + 2];
     for (uint32_t sidx = 0; sidx < b.n_samp; ++sidx) {
         const size_t i = (size_t)sidx * b.n_pix + pl;
-        r = r + radiance[3 * i];
-        g = g + radiance[3 * i + 1];
-        bl = bl + radiance[3 * i + 2];
+        r = r + radiance[i];
+        g = g + radiance[P + i];
+        bl = bl + radiance[2 * P + i];
     }
     accum[3 * pix] = r;
     accum[3 * pix + 1] = g;
@@ -759,6 +767,17 @@ __global__ void k_sum_counts(const uint32_t *counts, int n, unsigned long long *
 // ---------------------------------------------------------------------------
 // Device scene
 // ---------------------------------------------------------------------------
+
+// A caller-provided block of device memory that render_core uses as its path
+// workspace instead of the scene's allocated one.
+struct FixedWorkspace {
+    void *ptr = nullptr;          // device address of the block
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;    // recorded at the end of every call that used it
+    std::mutex mu;                // calls take turns on the host
+    bool ready = false;
+};
+
 namespace {
 
 template <typename T>
@@ -840,7 +859,6 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
         return fail(RT_ERR_INVALID, "BVH was built for a different triangle count");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
-
     // an error return below releases whatever was uploaded so far
     struct Release {
         void operator()(Scene *p) const { scene_destroy(p); }
@@ -858,7 +876,7 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     FlatScene flat;
     rt_status st = flatten(mesh, bvh, flat);
     if (st != RT_OK) return st;
-    find_light(mesh, bvh.order, sc->light);
+    find_light(mesh, sc->light);
 
     if ((st = upload(&sc->d_nodes, flat.nodes.data(), flat.nodes.size() * 4)) != RT_OK) return st;
     {
@@ -954,8 +972,9 @@ rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_
 }
 
 void workspace_free(Scene &sc) {
-    for (void *p : sc.ws_allocs) (void)hipFree(p);
-    sc.ws_allocs.clear();
+    if (sc.ws_block) (void)hipFree(sc.ws_block);
+    sc.ws_block = nullptr;
+    sc.ws_block_bytes = 0;
     sc.ws_paths = 0;
 }
 
@@ -1018,10 +1037,14 @@ static uint32_t *next_cursor(Scene &sc) {
 
 rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,
                        rt_hit *d_hits, int mode, unsigned long long *d_counters,
-                       hipStream_t stream) {
+                       hipStream_t stream, uint32_t *d_cursor) {
     if (n_host == 0) return RT_OK;
     if (n_host > 0x7fffffffULL) return fail(RT_ERR_INVALID, "more than 2^31-1 rays in one call");
-    uint32_t *cursor = next_cursor(sc);
+    // the cursor reset and the launch must go to the scene's device whatever device
+    // the calling thread has current (`stream` must belong to the scene's device)
+    DeviceGuard guard(sc.device);
+    if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    uint32_t *cursor = d_cursor ? d_cursor : next_cursor(sc);
     HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
     const DevScene d = dev_view(sc);
     const dim3 grid(trace_grid(sc, n_host)), block(256);
@@ -1133,55 +1156,89 @@ rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits,
     return RT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Path workspace: every per-batch buffer is a range of ONE block of device
+// memory, so that the block can come from hipMalloc (grow-only, kept by the
+// scene) or from the library's static device array alike.
+// ---------------------------------------------------------------------------
+struct WsLayout {
+    size_t rays[2], hits[2], counts, head, slots, terms_a, terms_b, radiance, ray_total, trav, cursor;
+    size_t total;
+};
+
+static WsLayout ws_layout(size_t P, int L, int B) {
+    const size_t Lc = (size_t)(L > 0 ? L : 1), qcap = P * (Lc + 1), nv = (size_t)B + 1;
+    WsLayout l{};
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    for (int i = 0; i < 2; ++i) {
+        l.rays[i] = take(qcap * sizeof(rt_ray));
+        l.hits[i] = take(qcap * sizeof(rt_hit));
+    }
+    l.counts = take(((size_t)B + 3) * sizeof(uint32_t));
+    l.head = take(P * sizeof(PathHead));
+    l.slots = take(P * Lc * sizeof(f4));
+    l.terms_a = take(P * nv * sizeof(f4));
+    l.terms_b = take(P * nv * sizeof(Pair32));
+    l.radiance = take(P * 3 * sizeof(float));
+    l.ray_total = take(64);
+    l.trav = take(8 * sizeof(unsigned long long));
+    l.cursor = take((size_t)kCursorStride * sizeof(uint32_t));
+    l.total = at;
+    return l;
+}
+
+static PathBuffers ws_carve(void *block, const WsLayout &l) {
+    char *base = static_cast<char *>(block);
+    PathBuffers b{};
+    for (int i = 0; i < 2; ++i) {
+        b.rays[i] = reinterpret_cast<rt_ray *>(base + l.rays[i]);
+        b.hits[i] = reinterpret_cast<rt_hit *>(base + l.hits[i]);
+    }
+    b.counts = reinterpret_cast<uint32_t *>(base + l.counts);
+    b.head = reinterpret_cast<PathHead *>(base + l.head);
+    b.slots = reinterpret_cast<f4 *>(base + l.slots);
+    b.terms_a = reinterpret_cast<f4 *>(base + l.terms_a);
+    b.terms_b = reinterpret_cast<Pair32 *>(base + l.terms_b);
+    b.radiance = reinterpret_cast<float *>(base + l.radiance);
+    b.ray_total = reinterpret_cast<unsigned long long *>(base + l.ray_total);
+    b.trav_counters = reinterpret_cast<unsigned long long *>(base + l.trav);
+    b.cursor = reinterpret_cast<uint32_t *>(base + l.cursor);
+    return b;
+}
+
+size_t workspace_bytes_per_path(int L, int B) {
+    const size_t Lc = (size_t)(L > 0 ? L : 1), nv = (size_t)(B > 0 ? B : 0) + 1;
+    return 2 * (Lc + 1) * (sizeof(rt_ray) + sizeof(rt_hit)) + sizeof(PathHead) + Lc * sizeof(f4) +
+           nv * (sizeof(f4) + sizeof(Pair32)) + 3 * sizeof(float);
+}
+
 // Grow-only workspace for `paths` simultaneous paths with L light samples and
-// B bounces; every buffer is reused across batches and calls.
+// B bounces, reused across batches and calls.
 static rt_status workspace_ensure(Scene &sc, size_t paths, int L, int B, PathBuffers &w) {
-    const size_t Lc = (size_t)(L > 0 ? L : 1);
     if (sc.ws_paths < paths || sc.ws_L < L || sc.ws_B < B) {
         workspace_free(sc);
-        const size_t P = paths, qcap = P * (Lc + 1);
-        bool out_of_memory = false;
-        auto alloc = [&](void **p, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-            if (e == hipSuccess) sc.ws_allocs.push_back(*p);
-            if (e == hipErrorOutOfMemory) {
-                out_of_memory = true;
-                (void)hipGetLastError();   // clear the sticky error so that a smaller retry can succeed
-            }
-            return e;
-        };
-        // an allocation that does not fit is reported as RT_ERR_NOMEM after the partial
-        // workspace is released, so that the caller can retry with a smaller batch
-#define WS_TRY(expr)                                                                      \
-        do {                                                                              \
-            hipError_t e__ = (expr);                                                      \
-            if (e__ != hipSuccess) {                                                      \
-                workspace_free(sc);                                                       \
-                return fail(out_of_memory ? RT_ERR_NOMEM : RT_ERR_DEVICE,                 \
-                            std::string(#expr) + ": " + hipGetErrorString(e__));          \
-            }                                                                             \
-        } while (0)
-        PathBuffers &b = sc.ws;
-        std::memset(&b, 0, sizeof b);
-        for (int i = 0; i < 2; ++i) {
-            WS_TRY(alloc(reinterpret_cast<void **>(&b.rays[i]), qcap * sizeof(rt_ray)));
-            WS_TRY(alloc(reinterpret_cast<void **>(&b.hits[i]), qcap * sizeof(rt_hit)));
+        const WsLayout l = ws_layout(paths, L, B);
+        // a block that does not fit (free device memory, or the scene's own bound)
+        // is reported as RT_ERR_NOMEM so that the caller can retry with a smaller batch
+        if (sc.ws_byte_limit && l.total > sc.ws_byte_limit)
+            return fail(RT_ERR_NOMEM, "path workspace of " + std::to_string(l.total) +
+                                          " bytes exceeds the scene's workspace limit");
+        void *block = nullptr;
+        const hipError_t e = hipMalloc(&block, l.total);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();   // clear the sticky error so that a smaller retry can succeed
+            return fail(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,
+                        std::string("hipMalloc of the path workspace: ") + hipGetErrorString(e));
         }
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.counts), (size_t)(B + 3) * sizeof(uint32_t) + 256));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.state), P));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.n_terms), P));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_ctr), P * 4));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.rng_stream), P * 8));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.bounce_q), P * 4));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_q), P * Lc * 4));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_dist), P * Lc * 4));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.shadow_col), P * Lc * 12));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.shading_terms), P * (size_t)(B + 1) * 12));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.brdf_terms), P * (size_t)(B + 1) * 12));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.radiance), P * 12));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.ray_total), 64));
-        WS_TRY(alloc(reinterpret_cast<void **>(&b.trav_counters), 64));
-#undef WS_TRY
+        sc.ws_block = block;
+        sc.ws_block_bytes = l.total;
+        sc.ws = ws_carve(block, l);
+        sc.ws.cursor = nullptr;        // allocated workspaces use the scene's cursor ring
         sc.ws_paths = paths;
         sc.ws_L = L;
         sc.ws_B = B;
@@ -1210,11 +1267,17 @@ static bool same_frame(const rt_pass &a, const rt_pass &b) {
            a.total_width == b.total_width && a.total_height == b.total_height;
 }
 
-rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
-                            int32_t sample_begin, int32_t sample_count, bool incremental,
-                            bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
-                            hipStream_t stream) {
+// The render loop behind every tile entry point.  `fixed` != nullptr: the path
+// workspace is that block (fixed_paths paths at most) instead of allocated
+// memory, and the call allocates nothing, neither on the device nor through
+// the HIP runtime (one pass, no statistics).
+static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
+                             int32_t sample_begin, int32_t sample_count, bool incremental,
+                             bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
+                             hipStream_t stream, FixedWorkspace *fixed, size_t fixed_paths) {
     DeviceGuard guard(sc.device);
+    if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    if (fixed && (stats || n_passes != 1)) return fail(RT_ERR_INVALID, "the static-workspace call takes one pass and no statistics");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (!passes || n_passes < 1) return fail(RT_ERR_INVALID, "no pass given");
     if (n_passes > 65536) return fail(RT_ERR_INVALID, "more than 65536 tiles in one call");
@@ -1247,32 +1310,47 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
     if (pixels > 0xffffffffULL) return fail(RT_ERR_INVALID, "more than 2^32-1 pixels in one call");
     const int L = pp.L, B = pp.B;
 
-    // one render call at a time per scene, on the host and on the GPU
-    std::lock_guard<std::mutex> lock(sc.render_mu);
-    HIP_TRY(hipStreamWaitEvent(stream, sc.ws_done, 0));
+    // one render call at a time per workspace, on the host and on the GPU: the
+    // scene's own, or the device's static one
+    std::mutex &mu = fixed ? fixed->mu : sc.render_mu;
+    hipEvent_t done = fixed ? fixed->done : sc.ws_done;
+    std::lock_guard<std::mutex> lock(mu);
+    HIP_TRY(hipStreamWaitEvent(stream, done, 0));
     struct MarkDone {
-        Scene &sc;
+        hipEvent_t done;
         hipStream_t stream;
-        ~MarkDone() { (void)hipEventRecord(sc.ws_done, stream); }
-    } mark_done{sc, stream};
+        ~MarkDone() { (void)hipEventRecord(done, stream); }
+    } mark_done{done, stream};
 
     // batch shape: whole pixel rows of the tile-linear range x as many samples as fit
-    const size_t max_paths = sc.max_paths_in_flight;
+    const size_t Lq = (size_t)(L > 0 ? L : 1) + 1;             // queue slots a path can fill per vertex
+    size_t max_paths = fixed ? fixed_paths : sc.max_paths_in_flight;
+    // a traversal launch takes at most 2^31-1 rays: the queue of one batch must stay below that
+    while (max_paths > 64 && max_paths * Lq > (size_t)0x7fffffff) max_paths /= 2;
+    if (max_paths * Lq > (size_t)0x7fffffff)
+        return fail(RT_ERR_INVALID, "LightSampleRays too large: a ray queue would exceed 2^31-1 rays");
     size_t n_pix = pixels < max_paths ? pixels : max_paths;
     size_t n_samp = max_paths / n_pix;
     if (n_samp < 1) n_samp = 1;
     if (n_samp > (size_t)sample_count) n_samp = (size_t)(sample_count > 0 ? sample_count : 1);
     PathBuffers w;
-    // the workspace is sized by the batch; when it does not fit in free device
-    // memory, halve the batch (down to 1M samples) and remember the smaller bound
-    for (;;) {
-        st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
-        if (st != RT_ERR_NOMEM || n_pix * n_samp <= ((size_t)1 << 20)) break;
-        if (n_samp > 1) n_samp = (n_samp + 1) / 2;
-        else n_pix = (n_pix + 1) / 2;
-        sc.max_paths_in_flight = n_pix * n_samp;
+    if (fixed) {
+        const WsLayout l = ws_layout(n_pix * n_samp, L, B);
+        if (l.total > fixed->bytes) return fail(RT_ERR_INVALID, "batch does not fit the given workspace block");
+        w = ws_carve(fixed->ptr, l);
+    } else {
+        // the workspace is sized by the batch; when it does not fit (free device
+        // memory, or the scene's workspace limit), halve the batch (down to 64 k
+        // samples) and remember the smaller bound
+        for (;;) {
+            st = workspace_ensure(sc, n_pix * n_samp, L, B, w);
+            if (st != RT_ERR_NOMEM || n_pix * n_samp <= ((size_t)1 << 16)) break;
+            if (n_samp > 1) n_samp = (n_samp + 1) / 2;
+            else n_pix = (n_pix + 1) / 2;
+            sc.max_paths_in_flight = n_pix * n_samp;
+        }
+        if (st != RT_OK) return st;
     }
-    if (st != RT_OK) return st;
     if (!tiles.empty()) {
         if (sc.tile_cap < tiles.size()) {
             if (sc.d_tiles) (void)hipFree(sc.d_tiles);
@@ -1289,8 +1367,10 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
 
     const DevScene d = dev_view(sc);
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
-    HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 8 * sizeof(unsigned long long), stream));
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
+        HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 8 * sizeof(unsigned long long), stream));
+    }
     EventPool events;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
@@ -1308,7 +1388,8 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             HIP_TRY(hipEventRecord(a, stream));
         }
         rt_status s2 = launch_trace(sc, rays, cap, cnt, hits, mode,
-                                    (stats && sc.count_traversal) ? w.trav_counters : nullptr, stream);
+                                    (stats && sc.count_traversal) ? w.trav_counters : nullptr, stream,
+                                    w.cursor);
         if (s2 != RT_OK) return s2;
         if (stats) HIP_TRY(hipEventRecord(b, stream));
         return RT_OK;
@@ -1336,7 +1417,7 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
             }
             hipLaunchKernelGGL(k_finish, grid, block, 0, stream, d, pp, b, w, (B + 1) & 1);
             hipLaunchKernelGGL(k_accumulate, dim3((b.n_pix + 255) / 256), block, 0, stream, b, w.radiance, d_accum);
-            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, w.counts, B + 2, w.ray_total);
+            if (stats) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, w.counts, B + 2, w.ray_total);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1390,6 +1471,14 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
         }
     }
     return RT_OK;
+}
+
+rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
+                            int32_t sample_begin, int32_t sample_count, bool incremental,
+                            bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
+                            hipStream_t stream) {
+    return render_core(sc, passes, n_passes, mode, sample_begin, sample_count, incremental, zero_accum,
+                       d_accum, d_rgba, stats, stream, nullptr, 0);
 }
 
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,

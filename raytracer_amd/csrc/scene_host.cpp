@@ -106,13 +106,16 @@ void make_tri_record(const float v[9], TriRecord &out) {
     }
 }
 
-void find_light(const rt_mesh &mesh, const std::vector<int32_t> &order, rt_light &out) {
+// The reference looks for the light inside RenderContext.Initialize
+// (context.go:180), before buildBVH / loadBVH sort the triangle array
+// (main.go:65-90): the walk is over the triangles in input (OBJ) order, and the
+// LAST "Light" triangle in that order sets normal, up and size.
+void find_light(const rt_mesh &mesh, rt_light &out) {
     std::memset(&out, 0, sizeof out);
     float mn[3] = {kF32Max, kF32Max, kF32Max}, mx[3] = {-kF32Max, -kF32Max, -kF32Max};
     float normal[3] = {0, 0, 0}, up[3] = {0, 0, 0}, shortest[3] = {0, 0, 0}, middle[3] = {0, 0, 0};
     bool found = false;
-    for (int32_t pos = 0; pos < mesh.n_tris; ++pos) {
-        int32_t id = order.empty() ? pos : order[(size_t)pos];
+    for (int32_t id = 0; id < mesh.n_tris; ++id) {
         int32_t mat = mesh.material ? mesh.material[id] : 0;
         if (!mesh.is_light[mat]) continue;
         found = true;

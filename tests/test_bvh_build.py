@@ -150,6 +150,51 @@ def test_binary_cache_round_trip(product_lib, tmp_path):
         api.Bvh.load(mesh, path)
 
 
+def test_binary_cache_rejects_stale_or_damaged_files(product_lib, tmp_path):
+    """The loader trusts nothing in the file: counts are checked against the
+    file size before anything is sized by them, depth is recomputed from the
+    preorder leaf flags, ranges and the triangle order are validated."""
+    import struct
+    sc = scenes.soup(500, seed=22)
+    mesh = product_mesh(sc)
+    b = api.Bvh.build(mesh, True, 4, 24)
+    path = str(tmp_path / "soup.bvh")
+    b.save(path)
+    good = open(path, "rb").read()
+    nn, nt = b.n_nodes, b.n_tris
+    hdr = 24
+    off = {"is_leaf": hdr, "start": hdr + 4 * nn, "end": hdr + 8 * nn, "depth": hdr + 12 * nn,
+           "order": hdr + nn * (16 + 12 + 12 + 16)}
+
+    def load_patched(data):
+        q = str(tmp_path / "patched.bvh")
+        with open(q, "wb") as f:
+            f.write(data)
+        return api.Bvh.load(mesh, q)
+
+    def patch(offset, fmt, *values):
+        raw = bytearray(good)
+        struct.pack_into(fmt, raw, offset, *values)
+        return bytes(raw)
+
+    # a stored depth array is not trusted: garbage there changes nothing
+    fixed = load_patched(patch(off["depth"], "<3i", 1 << 30, -7, 99)).export()
+    assert _same(b.export(), fixed) and fixed["depth"].max() == b.max_depth
+    bad = {
+        "huge node count": patch(12, "<i", 1 << 30),
+        "truncated": good[:-40],
+        "trailing bytes": good + b"\0" * 8,
+        "leaf flag flipped (tree no longer complete)": patch(off["is_leaf"], "<i", 1),
+        "range outside the array": patch(off["end"] + 4 * (nn - 1), "<i", nt + 5),
+        "order not a permutation": patch(off["order"], "<2i", 3, 3),
+        "negative start": patch(off["start"] + 4, "<i", -1),
+    }
+    for what, data in bad.items():
+        with pytest.raises(api._capi.RtError) as e:
+            load_patched(data)
+        assert e.value.status == -4, what
+
+
 def test_mesh_validation(product_lib):
     v = scenes.soup(4, seed=1)["verts"].copy()
     v[2, 4] = np.nan

@@ -212,42 +212,68 @@ def test_textured_room_bit_exact(product_lib, oracle, gpu_device):
     assert not np.array_equal(plain.render_tile(oracle.pass_from_dict(d))["rgba"], ref["rgba"])
 
 
-def test_batch_shrinks_when_device_memory_is_short(cornell_pair):
-    """The path workspace is sized by the batch (about 370 bytes per camera
-    sample at 4 bounces).  With almost all device memory taken, a frame whose
-    default batch would not fit is rendered in smaller batches instead of
-    failing, and the image does not change."""
+def test_batch_shrinks_when_the_workspace_does_not_fit(cornell_pair):
+    """The path workspace is sized by the batch.  When it does not fit -- free
+    device memory, or the scene's own workspace limit, which is what this test
+    sets so that no other process on the GPU is starved -- the frame is
+    rendered in smaller batches instead of failing, and the image does not
+    change."""
     import torch
     scene, _osc = cornell_pair
-    W, H = 2048, 1536                       # 3.1M samples per spp, about 1.2 GB of workspace
-    d = scenes.make_pass_dict(W, H, CORNELL_CAM, spp=2, bounces=4, light_samples=1,
+    W, H = 1024, 768
+    d = scenes.make_pass_dict(W, H, CORNELL_CAM, spp=4, bounces=4, light_samples=1,
                               intensity=100.0, seed=3)
     p = api.pass_from_dict(d)
     accum = torch.empty((W * H * 3,), dtype=torch.float32, device="cuda")
     rgba_a = torch.zeros((W * H * 4,), dtype=torch.uint8, device="cuda")
     rgba_b = torch.zeros_like(rgba_a)
     stream = torch.cuda.current_stream().cuda_stream
-    scene.set_max_paths(1 << 23)
     scene.render_tile_device(p, accum.data_ptr(), rgba_a.data_ptr(), stream=stream, want_stats=True)
     torch.cuda.synchronize()
-    # a fresh scene handle (no workspace yet) with only ~0.9 GB of device memory left
+    # a fresh scene handle (no workspace yet) that may only take 40 MB: the 3.1 M samples
+    # of the frame need about 1.1 GB in one batch
+    per_path = api.workspace_bytes_per_path(1, 4)
+    assert 300 <= per_path <= 420
     sc = cornell()
     mesh = product_mesh(sc)
     bvh = api.Bvh.build(mesh, True, 6, 16)
     scene2 = api.Scene(mesh, bvh, torch.cuda.current_device())
-    scene2.set_max_paths(1 << 23)
-    torch.cuda.empty_cache()
-    free, _total = torch.cuda.mem_get_info()
-    hog = torch.empty((max(free - (900 << 20), 0),), dtype=torch.uint8, device="cuda")
-    try:
-        st = scene2.render_tile_device(p, accum.data_ptr(), rgba_b.data_ptr(), stream=stream,
-                                       want_stats=True)
-        torch.cuda.synchronize()
-    finally:
-        del hog
-        torch.cuda.empty_cache()
-    assert st["rays"] > W * H * 2
+    scene2.set_workspace_limit(40 << 20)
+    before = torch.cuda.mem_get_info()[0]
+    st = scene2.render_tile_device(p, accum.data_ptr(), rgba_b.data_ptr(), stream=stream,
+                                   want_stats=True)
+    torch.cuda.synchronize()
+    assert before - torch.cuda.mem_get_info()[0] <= (48 << 20)
+    assert st["rays"] > W * H * 4
+    assert st["kernel_launches"] > 6 * (W * H * 4 * per_path // (40 << 20))   # many batches
     assert torch.equal(rgba_a, rgba_b)
+    # a limit too small for even the smallest batch is an error, not a crash
+    scene2.set_workspace_limit(1 << 20)
+    scene3 = api.Scene(mesh, bvh, torch.cuda.current_device())
+    scene3.set_workspace_limit(1 << 20)
+    with pytest.raises(api._capi.RtError) as e:
+        scene3.render_tile_device(p, accum.data_ptr(), rgba_b.data_ptr(), stream=stream)
+    assert e.value.status == -3
+
+
+def test_bounce_limit_255_on_a_closed_box(product_lib, oracle, gpu_device):
+    """BounceLimit is a uint8 in the reference: 255 is legal, and inside a closed
+    room a path survives all 256 vertices.  Term counts up to 256 must fit the
+    per-path word, and the fold must run over all of them."""
+    sc = scenes.room_mesh(40, seed=5)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 4, 24)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    tabs = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
+    osc.set_sample_tables(*tabs)
+    d = scenes.make_pass_dict(24, 16, sc["camera"], spp=1, bounces=255, light_samples=1,
+                              intensity=6.0, seed=9)
+    out = scene.render_tile(api.pass_from_dict(d))
+    ref = osc.render_tile(oracle.pass_from_dict(d))
+    _compare(out, ref)
+    # many paths do reach the last vertex (1 primary + up to 256 shadow + 255 bounce rays each)
+    assert out["stats"]["rays"] > 24 * 16 * 200
 
 
 def test_render_calls_on_one_scene_take_turns(cornell_pair):

@@ -1,0 +1,180 @@
+"""The reference's own known-answer vectors (models/aabb_test.go:10-84, kept as
+data in tests/golden/aabb_kat.json) and the hand-derived triangle vectors
+(tests/golden/tri_kat.json, build-generated) driven through the KERNELS' code
+paths, not only through the oracle: on the CPU through the lane-serial build of
+the kernels' arithmetic header, on the GPU through rt_trace_rays in all three
+modes.
+
+Box vectors: a tree is loaded from the reference's JSON hand-over format whose
+left leaf carries exactly the vector's box (the unit cube) and holds one large
+triangle placed behind the cube, square to the ray; the right leaf's box lies
+inside the cube and its triangle is far away.  The root's own box is never
+tested (trace.go:139), so the ray reports a hit if and only if the cube's slab
+test passed -- what the vector pins."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+from util import GOLDEN
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _box_cases():
+    kat = _load("aabb_kat.json")
+    out = []
+    for case in kat["cases"]:
+        o = np.array(case["origin"], np.float32)
+        # axis.Mul(-1): float32 negation, gives -0 components (aabb_test.go:64)
+        d = o * np.float32(-1) if case.get("dir_is_negated_origin") else np.array(case["dir"], np.float32)
+        out.append((case, o, d))
+    return kat["box"], out
+
+
+def _target_behind_the_cube(oracle, o, d):
+    """A large triangle in the plane 3 units along the ray, facing it (front
+    face for the one-sided test), confirmed with the oracle's triangle test."""
+    d64 = d.astype(np.float64)
+    axis = int(np.argmax(np.abs(d64)))
+    e1, e2 = np.eye(3)[(axis + 1) % 3], np.eye(3)[(axis + 2) % 3]
+    c = o.astype(np.float64) + 3.0 * d64 / np.abs(d64[axis])
+    v0, v1, v2 = c - 40 * e1 - 40 * e2, c + 80 * e1 - 40 * e2, c - 40 * e1 + 80 * e2
+    t, _, _ = oracle.tri_intersect(v0, v1, v2, o, d)
+    if not t > 0:
+        v1, v2 = v2, v1
+        t, _, _ = oracle.tri_intersect(v0, v1, v2, o, d)
+    assert t == 3.0, "the target must be hit whenever it is tested"
+    return np.concatenate([v0, v1, v2]).astype(np.float32)
+
+
+def _cube_tree_json(box):
+    leaf = lambda s, mn, mx, idx: {"Depth": 1, "Index": idx, "LeftChild": None, "RightChild": None,
+                                   "Bounds": {"Bounds": [mn, mx]}, "StartIndex": s, "EndIndex": s,
+                                   "SplitPlane": [0, 0, 0, 0]}
+    return json.dumps({"Root": {
+        "Depth": 0, "Index": 0, "Bounds": {"Bounds": [[-2000, -2000, -2000], [2000, 2000, 2000]]},
+        "StartIndex": 0, "EndIndex": 1, "SplitPlane": [1, 0, 0, 500.0],
+        "LeftChild": leaf(0, box["min"], box["max"], 1),
+        "RightChild": leaf(1, [0.0, 0.0, 0.0], [0.125, 0.125, 0.125], 2)}})
+
+
+def _cube_scene(oracle, box, o, d):
+    target = _target_behind_the_cube(oracle, o, d)
+    far = np.float32([1000, 1000, 1000, 1000.5, 1000, 1000, 1000, 1000.5, 1000])
+    mesh = api.Mesh(np.stack([target, far]))
+    bvh = api.Bvh.from_json(mesh, _cube_tree_json(box))
+    e = bvh.export()
+    assert e["order"].tolist() == [0, 1]
+    assert e["bmin"][1].tolist() == box["min"] and e["bmax"][1].tolist() == box["max"]
+    return mesh, bvh
+
+
+def _emul(emul, bvh, rays, mode, counters=False):
+    hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
+    cnt = np.zeros(5, np.uint64)
+    _, tris, _ = bvh.flatten()
+    if mode == api.MODE_FAST_F32:
+        rec, root = bvh.flatten_ordered()
+        emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
+                             tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                             rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
+                             hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+    else:
+        nodes, _, _ = bvh.flatten()
+        emul.emul_trace(nodes.ctypes.data_as(C.c_void_p), C.c_int32(nodes.shape[0]),
+                        tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
+                        rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]), C.c_int(mode),
+                        hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+    return hits, int(cnt[3])
+
+
+MODES = [api.MODE_STRICT_F32, api.MODE_FP64, api.MODE_FAST_F32]
+
+
+def _run_box_vectors(oracle, trace):
+    box, cases = _box_cases()
+    assert len(cases) == 10
+    for case, o, d in cases:
+        mesh, bvh = _cube_scene(oracle, box, o, d)
+        rays = api.make_rays(o[None, :], d[None, :])
+        for mode in MODES:
+            hit = trace(mesh, bvh, rays, mode)[0][0]
+            got = int(hit["tri_pos"]) == 0
+            assert got == case["hit"], (case["name"], mode)
+            if got:
+                assert float(hit["t"]) == 3.0, (case["name"], mode)
+        if "tmin" in case:
+            # TestRayAABBDistance: the slab interval starts at exactly 0.5.  A leaf is entered when
+            # "boxTmin < tmin" (bvh.go:134), so a cast limited to tmin = 0.5 must not fetch the
+            # target and one limited to the next float above 0.5 must (the target itself, at t = 3,
+            # lies beyond either limit: no triangle is reported).  The ordered mode tests a box
+            # that contains the cube, so only the entered side is pinned there.
+            for tmax, entered in [(np.float32(0.5), False), (np.nextafter(np.float32(0.5), np.float32(1)), True)]:
+                for mode in MODES:
+                    r2 = rays.copy()
+                    r2["tmax"] = tmax
+                    hits, fetched = trace(mesh, bvh, r2, mode, counters=True)
+                    assert int(hits[0]["tri_pos"]) == -1 and float(hits[0]["t"]) == float(tmax), mode
+                    if entered or mode != api.MODE_FAST_F32:
+                        assert (fetched >= 1) == entered, (mode, float(tmax), fetched)
+
+
+def _run_triangle_vectors(trace):
+    kat = _load("tri_kat.json")
+    tri = kat["triangle"]
+    verts = np.float32([tri["v0"] + tri["v1"] + tri["v2"]])
+    mesh = api.Mesh(verts)
+    bvh = api.Bvh.build(mesh, False, 6, 16)          # one leaf, entered without a box test
+    for case in kat["cases"]:
+        rays = api.make_rays(np.float32([case["origin"]]), np.float32([case["dir"]]))
+        for mode in MODES:
+            hit = trace(mesh, bvh, rays, mode)[0][0]
+            if case["t"] > 0:
+                assert (int(hit["tri_pos"]), float(hit["t"]), float(hit["u"]), float(hit["v"])) == \
+                    (0, case["t"], case["u"], case["v"]), (case["name"], mode)
+            else:
+                # rejected by the test itself (t = -1), culled, or behind the origin (t <= 0)
+                assert int(hit["tri_pos"]) == -1, (case["name"], mode)
+    assert sum(1 for c in kat["cases"] if c["t"] > 0) >= 4
+
+
+def test_box_vectors_through_the_kernel_arithmetic_on_the_cpu(product_lib, oracle, emul):
+    _run_box_vectors(oracle, lambda mesh, bvh, rays, mode, counters=False: _emul(emul, bvh, rays, mode))
+
+
+def test_triangle_vectors_through_the_kernel_arithmetic_on_the_cpu(product_lib, emul):
+    _run_triangle_vectors(lambda mesh, bvh, rays, mode, counters=False: _emul(emul, bvh, rays, mode))
+
+
+@pytest.mark.gpu
+def test_box_vectors_through_the_kernels(product_lib, oracle, gpu_device):
+    scenes = {}
+
+    def trace(mesh, bvh, rays, mode, counters=False):
+        key = id(bvh)
+        if key not in scenes:
+            scenes[key] = (api.Scene(mesh, bvh, gpu_device), bvh)
+        hits, st = scenes[key][0].trace_rays(rays, mode=mode, counters=counters)
+        return hits, st["tris_fetched"]
+
+    _run_box_vectors(oracle, trace)
+
+
+@pytest.mark.gpu
+def test_triangle_vectors_through_the_kernels(product_lib, gpu_device):
+    scenes = {}
+
+    def trace(mesh, bvh, rays, mode, counters=False):
+        if id(bvh) not in scenes:
+            scenes[id(bvh)] = (api.Scene(mesh, bvh, gpu_device), bvh)
+        hits, st = scenes[id(bvh)][0].trace_rays(rays, mode=mode, counters=counters)
+        return hits, st["tris_fetched"]
+
+    _run_triangle_vectors(trace)
