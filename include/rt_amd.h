@@ -329,6 +329,25 @@ rt_status rt_render_tiles_device(rt_scene *scene, const rt_pass *passes, int32_t
 rt_status rt_render_accumulate(rt_scene *scene, const rt_pass *pass, int32_t mode,
                                int32_t sample_begin, int32_t sample_count, void *d_accum,
                                void *d_rgba, rt_stats *stats, void *stream);
+/* One tile like rt_render_tile_device, for callers that cannot allocate: code
+ * under HIP graph capture, tight serving loops that render one small tile per
+ * request, harnesses that forbid allocation.  It has no counterpart in the
+ * reference.  The call allocates nothing (no hipMalloc / hipFree, no event or
+ * stream creation): the path workspace is a static device array of
+ * RT_STATIC_WORKSPACE_BYTES that every GPU the library runs on holds until
+ * the process ends.  The tile is traced in as many sample batches as that
+ * array allows; a tile whose pixel count times
+ * rt_workspace_bytes_per_path(LightSampleRays, BounceLimit) exceeds it is
+ * refused with RT_ERR_INVALID.  Results equal rt_render_tile_device's bit for
+ * bit.  No statistics are returned (they would need a read-back).  All calls
+ * on one GPU share that GPU's array: calls from several threads take turns on
+ * the host and each waits on the GPU for the one before it, but calls issued
+ * while an earlier one is still being CAPTURED into a graph, or replays of
+ * captured graphs that overlap, race on it.  d_accum (width*height*3 f32,
+ * zeroed by the call) and d_rgba (width*height*4) are device pointers. */
+#define RT_STATIC_WORKSPACE_BYTES (64u << 20)
+rt_status rt_render_tile_static(rt_scene *scene, const rt_pass *pass, int32_t mode,
+                                void *d_accum, void *d_rgba, void *stream);
 /* main.go:158-182 on a device accumulation buffer. */
 rt_status rt_resolve_device(const void *d_accum, size_t pixels, int32_t divisor,
                             int32_t gamma_on, float gamma, void *d_rgba, void *stream);

@@ -112,6 +112,7 @@ SIGNATURES = {
                                            C.POINTER(Stats), vp]),
     "rt_render_accumulate": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, C.c_int32, C.c_int32,
                                          vp, vp, C.POINTER(Stats), vp]),
+    "rt_render_tile_static": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp, vp]),
     "rt_resolve_device": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.c_int32, C.c_float, vp, vp]),
 }
 

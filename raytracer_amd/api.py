@@ -153,6 +153,9 @@ class Bvh:
             self._h = None
 
 
+STATIC_WORKSPACE_BYTES = 64 << 20
+
+
 def workspace_bytes_per_path(light_sample_rays, bounce_limit):
     return int(lib().rt_workspace_bytes_per_path(light_sample_rays, bounce_limit))
 
@@ -279,6 +282,10 @@ class Scene:
         check(lib().rt_render_tile_device(self._h, C.byref(p), mode, d_accum_ptr, d_rgba_ptr,
                                           C.byref(st) if st is not None else None, stream))
         return st.as_dict() if st is not None else None
+
+    def render_tile_static(self, p, d_accum_ptr, d_rgba_ptr, mode=MODE_STRICT_F32, stream=None):
+        """One tile with the library's static device workspace: allocates nothing."""
+        check(lib().rt_render_tile_static(self._h, C.byref(p), mode, d_accum_ptr, d_rgba_ptr, stream))
 
     def render_tiles_device(self, passes, d_accum_ptr, d_rgba_ptr, mode=MODE_STRICT_F32,
                             stream=None, want_stats=False):

@@ -393,6 +393,15 @@ rt_status rt_render_tiles_device(rt_scene *scene, const rt_pass *passes, int32_t
     RT_GUARD_END
 }
 
+rt_status rt_render_tile_static(rt_scene *scene, const rt_pass *pass, int32_t mode, void *d_accum,
+                                void *d_rgba, void *stream) {
+    RT_GUARD_BEGIN
+    if (!scene || !scene->impl || !pass) return fail(RT_ERR_INVALID, "NULL argument");
+    return rt::render_tile_static(*scene->impl, *pass, mode, static_cast<float *>(d_accum),
+                                  static_cast<uint8_t *>(d_rgba), static_cast<hipStream_t>(stream));
+    RT_GUARD_END
+}
+
 rt_status rt_resolve_device(const void *d_accum, size_t pixels, int32_t divisor, int32_t gamma_on,
                             float gamma, void *d_rgba, void *stream) {
     RT_GUARD_BEGIN

@@ -122,6 +122,10 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
                             int32_t sample_begin, int32_t sample_count, bool incremental,
                             bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
                             hipStream_t stream);
+// One tile with the path workspace taken from the library's static device
+// array instead of allocated memory; calls nothing that allocates.
+rt_status render_tile_static(Scene &sc, const rt_pass &pass, int mode, float *d_accum,
+                             uint8_t *d_rgba, hipStream_t stream);
 // Bytes of path workspace one camera sample in flight takes at these settings.
 size_t workspace_bytes_per_path(int light_samples, int bounce_limit);
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,

@@ -32,6 +32,14 @@
 
 using namespace rtc;
 
+// Static device workspace of the entry point that must not allocate
+// (rt_render_tile_static): one copy per GPU the code object is loaded on, held
+// until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; every use of its memory goes through the per-device
+// address obtained once at set-up (rt::FixedWorkspace::ptr).
+constexpr size_t kStaticScratchBytes = (size_t)RT_STATIC_WORKSPACE_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace rt {
 
 #define HIP_TRY(expr)                                                                    \
@@ -778,6 +786,29 @@ struct FixedWorkspace {
     bool ready = false;
 };
 
+// Per-device state of the static workspace (the `scratch` array at the top of
+// this file).
+constexpr int kMaxDevices = 64;
+static FixedWorkspace g_static[kMaxDevices];
+static std::mutex g_static_mu;
+
+// Once per device, with that device current (scene creation is the library's
+// per-device set-up call).
+static rt_status static_scratch_setup(int device) {
+    if (device < 0 || device >= kMaxDevices) return RT_OK;   // such a device simply has no static workspace
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    FixedWorkspace &ds = g_static[device];
+    if (ds.ready) return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the static workspace");
+    HIP_TRY(hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
+    ds.ptr = p;
+    ds.bytes = kStaticScratchBytes;
+    ds.ready = true;
+    return RT_OK;
+}
+
 namespace {
 
 template <typename T>
@@ -859,6 +890,11 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
         return fail(RT_ERR_INVALID, "BVH was built for a different triangle count");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    {
+        const rt_status ss = static_scratch_setup(device);
+        if (ss != RT_OK) return ss;
+    }
+
     // an error return below releases whatever was uploaded so far
     struct Release {
         void operator()(Scene *p) const { scene_destroy(p); }
@@ -1479,6 +1515,30 @@ rt_status render_accumulate(Scene &sc, const rt_pass *passes, int32_t n_passes, 
                             hipStream_t stream) {
     return render_core(sc, passes, n_passes, mode, sample_begin, sample_count, incremental, zero_accum,
                        d_accum, d_rgba, stats, stream, nullptr, 0);
+}
+
+rt_status render_tile_static(Scene &sc, const rt_pass &pass, int mode, float *d_accum, uint8_t *d_rgba,
+                             hipStream_t stream) {
+    if (sc.device < 0 || sc.device >= kMaxDevices || !g_static[sc.device].ready)
+        return fail(RT_ERR_STATE, "the static workspace of this device was not set up");
+    if (!d_rgba) return fail(RT_ERR_INVALID, "rgba is NULL");
+    if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
+    const int L = pass.settings.light_sample_rays, B = pass.settings.bounce_limit & 0xff;
+    if (L < 0) return fail(RT_ERR_INVALID, "LightSampleRays is negative");
+    // the largest batch whose buffers fit the array (every buffer starts on a 256-byte boundary)
+    const size_t per_path = workspace_bytes_per_path(L, B);
+    size_t paths = kStaticScratchBytes / per_path;
+    while (paths > 0 && ws_layout(paths, L, B).total > kStaticScratchBytes) paths -= paths > 64 ? 64 : 1;
+    const size_t pixels = (size_t)pass.width * (size_t)pass.height;
+    if (pixels > paths)
+        return fail(RT_ERR_INVALID,
+                    "tile too large for the static workspace: " + std::to_string(pixels) + " pixels x " +
+                        std::to_string(per_path) + " bytes per path at LightSampleRays " + std::to_string(L) +
+                        ", BounceLimit " + std::to_string(B) + " exceed its " +
+                        std::to_string(kStaticScratchBytes) + " bytes (at most " + std::to_string(paths) +
+                        " pixels per call at these settings)");
+    return render_core(sc, &pass, 1, mode, 0, pass.camera.rays_per_pixel, false, true, d_accum, d_rgba,
+                       nullptr, stream, &g_static[sc.device], paths);
 }
 
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
