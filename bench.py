@@ -33,6 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0
+# VALU lane-instruction issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz
+VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
+INFINITY_CACHE_MB = 256.0
 
 WORKLOADS = {
     # name: grid, triangles, width, height, tiles per dim, leaf, depth, intensity
@@ -72,6 +75,7 @@ def parse_args():
                     help="ranks pull tiles from a shared counter instead of the static block-cyclic deal")
     ap.add_argument("--chunk", type=int, default=8, help="tiles taken per pull with --dynamic")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
+    ap.add_argument("--opt", default="", help="scene options name=value,... (experiments; see rt_scene_set_option)")
     ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
     ap.add_argument("--pretend-world", type=int, default=0,
                     help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
@@ -128,20 +132,74 @@ def cpu_baseline(sc, bvh_export, tables, wl, args, tile_list):
                 state["rays"] += out["counters"]["rays"]
                 state["tiles"] += 1
 
-    state, dt = timed(n_threads, args.cpu_seconds)
+    state, dt = timed(n_threads, args.cpu_seconds * 0.4)
+    # every core this process may run on, one thread per core (capped at the tile count)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    n_all = max(1, min(usable, len(order)))
+    every, dt_all = timed(n_all, args.cpu_seconds * 0.4)
     # the same tiles on ONE thread (the reference runs one wasm instance per worker), a few seconds
-    one, dt1 = timed(1, min(4.0, args.cpu_seconds / 4))
+    one, dt1 = timed(1, min(4.0, args.cpu_seconds * 0.2))
     return {"value": state["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": n_threads,
             "kind": "port",
+            "all_cores_value": round(every["rays"] / dt_all / 1e6, 3),
+            "all_cores": n_all, "os_cpu_count": os.cpu_count(),
             "single_core_value": round(one["rays"] / dt1 / 1e6, 3) if one["rays"] else None,
+            "go": go_baseline(),
             "sample": f"{state['tiles']} of {len(tile_list)} tiles of the same frame at 1 spp, "
                       f"{state['rays']} rays in {dt:.1f} s, scalar C restatement of the "
-                      f"reference algorithm, one thread per tile worker; single_core_value: "
-                      f"{one['tiles']} tiles, {one['rays']} rays in {dt1:.1f} s on one thread"}
+                      f"reference algorithm, one thread per tile worker ({n_threads} threads: the preset's 16 "
+                      f"workers); all_cores_value: {every['tiles']} tiles, {every['rays']} rays in {dt_all:.1f} s "
+                      f"on {n_all} threads (cores this process may use; the machine reports {os.cpu_count()}); "
+                      f"single_core_value: {one['tiles']} tiles, {one['rays']} rays in {dt1:.1f} s on one thread"}
+
+
+def go_baseline():
+    """The stdlib-only Go restatement (go/cpu_restatement) keeps the reference's
+    data layout -- pointer tree, []*Triangle, a heap-allocated ray per cast -- to
+    price "Go on the CPU" honestly.  It needs a Go toolchain, which the build
+    environment lacks; when `go version` works it is built and run on its own
+    synthetic scene, otherwise the field says so."""
+    import shutil
+    import subprocess
+    if shutil.which("go") is None:
+        return "absent"
+    src = os.path.join(ROOT, "go", "cpu_restatement")
+    try:
+        out = subprocess.run(["go", "run", ".", "-tris", "100000", "-rays", "2000000"], cwd=src,
+                             capture_output=True, text=True, timeout=180)
+        if out.returncode != 0:
+            return {"error": out.stderr[-300:]}
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001 - reported in the line, never fatal for the bench
+        return {"error": str(e)[:300]}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with
+    torch.distributed.run as a CHILD process (the parent has not touched the GPU
+    and never execs) and hand its exit code on.  Never falls back to one rank."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()          # does not initialise the GPU
+    if args.backend == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {n_dev} GPU(s) visible; refusing to run fewer ranks "
+                         f"than asked for (use --backend gloo to rehearse several ranks on one GPU)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     from raytracer_amd import api, scenes, tiles
@@ -149,7 +207,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
@@ -176,6 +234,9 @@ def main():
     setup_s = time.perf_counter() - t0
     if args.tune:
         scene.set_tuning(*[int(x) for x in args.tune.split(",")])
+    for kv in filter(None, args.opt.split(",")):
+        k, v = kv.split("=")
+        scene.set_option(k, int(v))
     if args.max_paths:
         scene.set_max_paths(args.max_paths)
     tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))

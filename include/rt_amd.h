@@ -145,6 +145,14 @@ typedef struct rt_scene_info {
     int32_t device;
     int32_t has_light;
     uint64_t node_bytes, tri_bytes, total_device_bytes;
+    uint64_t ordered_bytes;          /* size of the 4-wide ordered view (0: none) */
+    /* which flat views of the tree the scene holds besides the plain preorder
+     * array: the linked reference-order view (needs leaves of at most 127
+     * triangles and triangle positions below 2^24; without it the reference-order
+     * kernel reads the preorder array), and the 4-wide ordered view (needs at
+     * most 2^24-2 triangles; without it RT_MODE_FAST_F32 runs the reference
+     * order) */
+    int32_t linked_view, ordered_view;
 } rt_scene_info;
 
 /* context.go:172-226 on the host, no device needed: the area light of a mesh.
@@ -204,6 +212,12 @@ uint64_t rt_workspace_bytes_per_path(int32_t light_sample_rays, int32_t bounce_l
  * do not depend on them. */
 rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
                               int32_t blocks_per_cu, int32_t descend_min, int32_t leaf_min);
+/* Further scheduling options of the ordered traversal, by name (results do not
+ * depend on them): "pair" 0/1 = one ray per lane (k_trace_fast) or two
+ * (k_trace_pair), "pair_stack" 4/6/8 = LDS stack entries per ray of the latter,
+ * "swap_desc" / "swap_leaf" 0..64 = a lane exchanges its two rays once fewer
+ * lanes than this can take part in the descent / leaf phase. */
+rt_status rt_scene_set_option(rt_scene *scene, const char *name, int32_t value);
 /* When enabled, render calls that return rt_stats run the counting variant of
  * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
  * tris_tested (slower; for the roofline byte model, not for timed runs). */
@@ -351,6 +365,14 @@ rt_status rt_render_tile_static(rt_scene *scene, const rt_pass *pass, int32_t mo
 /* main.go:158-182 on a device accumulation buffer. */
 rt_status rt_resolve_device(const void *d_accum, size_t pixels, int32_t divisor,
                             int32_t gamma_on, float gamma, void *d_rgba, void *stream);
+
+/* Measurement aid (no counterpart in the reference): the rate, in records
+ * per second, at which every lane of the GPU can chase random 64-byte records
+ * through a table of table_bytes (dependent loads, four 16-byte loads per
+ * record, full occupancy) -- the access pattern of tree traversal in
+ * isolation, and so the ceiling the cache hierarchy sets for it.  Allocates
+ * and frees the table; takes a few milliseconds. */
+rt_status rt_gather_probe(int32_t device, size_t table_bytes, double *records_per_s);
 
 #ifdef __cplusplus
 }

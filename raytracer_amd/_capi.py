@@ -33,7 +33,9 @@ class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_int32), ("n_nodes", C.c_int32), ("max_depth", C.c_int32),
                 ("n_materials", C.c_int32), ("device", C.c_int32), ("has_light", C.c_int32),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64),
-                ("total_device_bytes", C.c_uint64)]
+                ("total_device_bytes", C.c_uint64), ("ordered_bytes", C.c_uint64),
+                ("linked_view", C.c_int32),
+                ("ordered_view", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -98,6 +100,7 @@ SIGNATURES = {
     "rt_scene_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
     "rt_workspace_bytes_per_path": (C.c_uint64, [C.c_int32, C.c_int32]),
     "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_scene_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int32]),
     "rt_scene_set_counters": (C.c_int32, [vp, C.c_int32]),
     "rt_scene_destroy": (None, [vp]),
     "rt_trace_rays": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, C.c_int32, C.POINTER(Stats)]),
@@ -113,6 +116,7 @@ SIGNATURES = {
     "rt_render_accumulate": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, C.c_int32, C.c_int32,
                                          vp, vp, C.POINTER(Stats), vp]),
     "rt_render_tile_static": (C.c_int32, [vp, C.POINTER(Pass), C.c_int32, vp, vp, vp]),
+    "rt_gather_probe": (C.c_int32, [C.c_int32, C.c_size_t, C.POINTER(C.c_double)]),
     "rt_resolve_device": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.c_int32, C.c_float, vp, vp]),
 }
 

@@ -160,6 +160,13 @@ def workspace_bytes_per_path(light_sample_rays, bounce_limit):
     return int(lib().rt_workspace_bytes_per_path(light_sample_rays, bounce_limit))
 
 
+def gather_probe(device, table_bytes):
+    """Random 64-byte record gathers per second through a table of that size."""
+    out = C.c_double()
+    check(lib().rt_gather_probe(device, int(table_bytes), C.byref(out)))
+    return out.value
+
+
 def default_sample_table(n, seed):
     out = np.zeros((n, 2), np.float64)
     check(lib().rt_default_sample_table(n, seed, _ptr(out)))
@@ -242,6 +249,9 @@ class Scene:
         """0 for a lane count = the kernel's own default."""
         check(lib().rt_scene_set_tuning(self._h, stack_entries, refill_below, blocks_per_cu, descend_min,
                                         leaf_min))
+
+    def set_option(self, name, value):
+        check(lib().rt_scene_set_option(self._h, name.encode(), int(value)))
 
     def set_counters(self, enabled):
         check(lib().rt_scene_set_counters(self._h, int(enabled)))

@@ -210,6 +210,19 @@ rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t re
     return RT_OK;
 }
 
+rt_status rt_scene_set_option(rt_scene *scene, const char *name, int32_t value) {
+    if (!scene || !scene->impl || !name) return fail(RT_ERR_INVALID, "NULL argument");
+    rt::Scene &sc = *scene->impl;
+    const std::string key(name);
+    if (key == "pair" && (value == 0 || value == 1)) sc.tune_pair = value;
+    else if (key == "pair_stack" && (value == 4 || value == 6 || value == 8)) sc.tune_pair_stack = value;
+    else if (key == "swap_desc" && value >= 0 && value <= 64) sc.tune_swap_desc = value;
+    else if (key == "swap_leaf" && value >= 0 && value <= 64) sc.tune_swap_leaf = value;
+    else if (key == "leaf_start" && value >= 1 && value <= 65) sc.tune_leaf_start = value;
+    else return fail(RT_ERR_INVALID, "unknown option or value out of range: " + key);
+    return RT_OK;
+}
+
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (max_paths < 64 || max_paths > ((uint64_t)1 << 28))
@@ -256,6 +269,9 @@ rt_status rt_scene_info_get(const rt_scene *scene, rt_scene_info *out) {
     out->has_light = s.light.found;
     out->node_bytes = s.node_bytes;
     out->tri_bytes = s.tri_bytes;
+    out->ordered_bytes = s.wide_bytes;
+    out->linked_view = s.d_linked ? 1 : 0;
+    out->ordered_view = s.d_wide ? 1 : 0;
     out->total_device_bytes = s.node_bytes * (s.d_linked ? 2 : 1) + s.wide_bytes + s.tri_bytes +
                               (uint64_t)s.n_tris * 16 + (uint64_t)(s.n_cam + s.n_light) * 16;
     return RT_OK;
@@ -399,6 +415,12 @@ rt_status rt_render_tile_static(rt_scene *scene, const rt_pass *pass, int32_t mo
     if (!scene || !scene->impl || !pass) return fail(RT_ERR_INVALID, "NULL argument");
     return rt::render_tile_static(*scene->impl, *pass, mode, static_cast<float *>(d_accum),
                                   static_cast<uint8_t *>(d_rgba), static_cast<hipStream_t>(stream));
+    RT_GUARD_END
+}
+
+rt_status rt_gather_probe(int32_t device, size_t table_bytes, double *records_per_s) {
+    RT_GUARD_BEGIN
+    return rt::gather_probe(device, table_bytes, records_per_s);
     RT_GUARD_END
 }
 

@@ -92,6 +92,11 @@ struct Scene {
     int tune_blocks_per_cu = 8;   // persistent grid size
     int tune_leaf_min = 0;        // leave the leaf phase below this many lanes in a leaf (0 = per-kernel default)
     int tune_descend_min = 0;     // leave the descent phase below this many descending lanes (0 = per-kernel default)
+    int tune_pair = 0;            // ordered mode: two rays per lane (k_trace_pair) instead of one
+    int tune_pair_stack = 8;      // its LDS stack entries per ray (4, 6 or 8)
+    int tune_swap_desc = 48;      // exchange a lane's rays once fewer lanes than this can descend ...
+    int tune_swap_leaf = 32;      // ... or hold a leaf
+    int tune_leaf_start = 65;     // the descent phase also ends once this many lanes hold a leaf ray (65: never)
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;
@@ -130,6 +135,7 @@ rt_status render_tile_static(Scene &sc, const rt_pass &pass, int mode, float *d_
 size_t workspace_bytes_per_path(int light_samples, int bounce_limit);
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
                            uint8_t *rgba, rt_stats *stats);
+rt_status gather_probe(int device, size_t table_bytes, double *records_per_s);
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
                          float gamma, uint8_t *d_rgba, hipStream_t stream);
 

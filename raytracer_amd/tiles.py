@@ -81,26 +81,67 @@ def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None):
     if rank != 0:
         return None
     for r, buf in enumerate(bufs):
-        mine = tile_list[r::world]
-        if _paste_uniform(frame, buf, mine):
-            continue
-        off = 0
-        for (_tid, x, y, w, h) in mine:
-            frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
-            off += w * h * 4
+        paste_tiles(frame, buf, tile_list[r::world])
     return frame
 
 
-def reduce_dynamic(local_frame, world, rank, group=None):
-    """Dynamic assignment: each rank pasted the tiles it happened to render into
-    its own zero-initialised full-size frame; tiles are disjoint, so a sum over
-    ranks is the composite.  Returns the frame on rank 0."""
+def paste_tiles(frame, buf, tiles):
+    """Tiles stored back to back in `buf` (uint8 RGBA) go to their offsets in
+    `frame` ((H, W, 4) uint8): one strided copy when they fit a lattice, a copy
+    per tile otherwise."""
+    if _paste_uniform(frame, buf, tiles):
+        return
+    off = 0
+    for (_tid, x, y, w, h) in tiles:
+        frame[y:y + h, x:x + w] = buf[off:off + w * h * 4].view(h, w, 4)
+        off += w * h * 4
+
+
+def gather_dynamic(local_rgba, my_ids, tile_list, world, rank, frame, group=None):
+    """Dynamic assignment: a rank holds the RGBA8 images of the tiles it happened
+    to pull, back to back in pull order, and the list of their ids.  One small
+    all-gather tells every rank who rendered what; then each rank sends exactly
+    its own pixels to rank 0 (point to point, no padding to the worst case and
+    no full-frame reduction), which pastes them.  Returns the frame on rank 0."""
+    n_tiles = len(tile_list)
+    dev = local_rgba.device
+    ids = torch.full((n_tiles,), -1, dtype=torch.int32, device=dev)
+    if my_ids:
+        ids[:len(my_ids)] = torch.tensor(my_ids, dtype=torch.int32, device=dev)
     if world > 1:
-        # widen so that the sum cannot overflow where a backend reduces in the tensor's dtype
-        wide = local_frame.to(torch.int32)
-        dist.reduce(wide, dst=0, op=dist.ReduceOp.SUM, group=group)
-        return wide.to(torch.uint8) if rank == 0 else None
-    return local_frame
+        all_ids = [torch.empty_like(ids) for _ in range(world)]
+        dist.all_gather(all_ids, ids, group=group)
+    else:
+        all_ids = [ids]
+    my_bytes = sum(tile_list[i][3] * tile_list[i][4] for i in my_ids) * 4
+    if rank != 0:
+        if my_bytes:
+            dist.send(local_rgba[:my_bytes], dst=0, group=group)
+        return None
+    owned = [[int(i) for i in t.tolist() if i >= 0] for t in all_ids]
+    seen = sorted(i for o in owned for i in o)
+    if seen != list(range(n_tiles)):
+        raise RuntimeError("the ranks' tile lists do not cover the frame exactly once")
+    bufs, reqs = [local_rgba], []
+    for r in range(1, world):
+        nbytes = sum(tile_list[i][3] * tile_list[i][4] for i in owned[r]) * 4
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        bufs.append(buf)
+        if nbytes:
+            reqs.append(dist.irecv(buf, src=r, group=group))
+    for q in reqs:
+        q.wait()
+    for r in range(world):
+        paste_tiles(frame, bufs[r], [tile_list[i] for i in owned[r]])
+    return frame
+
+
+def pull_chunk(n_tiles, world, samples_per_tile, target_samples=32 << 20):
+    """Tiles per pull of the dynamic queue: enough for a render call of about
+    `target_samples` camera samples (small calls run the GPU half empty), but
+    never so many that a rank gets fewer than two pulls."""
+    want = max(1, -(-target_samples // max(1, samples_per_tile)))
+    return max(1, min(want, n_tiles // max(1, 2 * world)))
 
 
 def sum_counters(values, device, world, group=None):

@@ -1,0 +1,197 @@
+"""GPU checks on the 10M-triangle configuration: 2236x2236 height field + room,
+seed 0x5EED0004, SAH leaf 8 depth 48, 7680x4320 frame in 32x32 tiles, 4
+bounces, 1 light sample.  The scene (about 1 GB on the device) does not fit the
+Infinity Cache, triangle positions need all 24 bits of the leaf encodings, and
+the frame has 33 M tile-linear pixels.
+
+The oracle renders whole tiles of the frame (bit-exact comparison of the
+reference-order mode); the ordered mode is compared with the reference order
+on 2 M incoherent rays, every differing ray classified; which node view the
+reference-order kernel reads is checked on both sides of the linked view's
+2^24 limit on triangle positions."""
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from util import classify_fast_differences, oracle_scene, product_mesh, rays6, record_parity_counts
+
+pytestmark = pytest.mark.gpu
+
+W, H, GRID = 7680, 4320, 32
+
+
+def _tables():
+    return api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02)
+
+
+@pytest.fixture(scope="module")
+def room_10m(product_lib, oracle, gpu_device):
+    sc = scenes.room_mesh(2236, seed=0x5EED0004, total=10_000_000)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 8, 48)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    return sc, mesh, bvh, scene
+
+
+def _pass_dict(sc, tile, spp=1, seed=1):
+    tid, x, y, w, h = tile
+    return scenes.make_pass_dict(W, H, sc["camera"], spp=spp, bounces=4, light_samples=1,
+                                 intensity=6.0, seed=seed, x_offset=x, y_offset=y, tile_w=w,
+                                 tile_h=h, task_id=tid)
+
+
+def test_cfg4_scene_views(room_10m):
+    sc, _mesh, bvh, scene = room_10m
+    assert bvh.n_tris == 10_000_000
+    info = scene.info()
+    # 10M triangles: positions below 2^24, so both the linked reference-order view and the
+    # ordered view exist
+    assert info["linked_view"] == 1 and info["ordered_view"] == 1
+    assert info["tri_bytes"] == 48 * 10_000_000
+    assert info["total_device_bytes"] > 900e6
+
+
+def test_cfg4_tiles_bit_exact_against_oracle(room_10m, oracle):
+    """Six whole 240x135 tiles of the 7680x4320 frame (rows and columns spread
+    over the 32x32 grid, the last row and column included), 1 spp: per-pixel
+    sums, RGBA bytes and ray counts of the reference-order mode equal the
+    oracle's."""
+    sc, _mesh, bvh, scene = room_10m
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    osc.set_sample_tables(*_tables())
+    tl = scenes.tiles(W, H, GRID)
+    assert len(tl) == GRID * GRID and sum(t[3] * t[4] for t in tl) == W * H
+    rays = 0
+    for r, c in [(0, 0), (7, 19), (15, 16), (16, 15), (25, 4), (31, 31)]:
+        tile = tl[r * GRID + c]
+        d = _pass_dict(sc, tile)
+        out = scene.render_tile(api.pass_from_dict(d))
+        ref = osc.render_tile(oracle.pass_from_dict(d))
+        assert np.array_equal(out["accum"].view(np.uint32), ref["accum"].view(np.uint32)), (r, c)
+        assert np.array_equal(out["rgba"], ref["rgba"]), (r, c)
+        assert out["stats"]["rays"] == ref["counters"]["rays"], (r, c)
+        rays += out["stats"]["rays"]
+    assert rays > 6 * 240 * 135 * 3
+
+
+def test_cfg4_incoherent_rays_strict_vs_fast(room_10m, oracle):
+    """2 M incoherent rays: the reference-order mode equals the oracle on a
+    sample of them bit for bit; the ordered mode differs from the reference order
+    on a counted handful, each a hit that the reference's box test pruned; t is
+    bit-equal where ids agree; hits lie in their triangles."""
+    sc, _mesh, bvh, scene = room_10m
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    half = 2236 * 0.05 / 2.0
+    rays = np.zeros(n, api.RAY_DTYPE)
+    rays["origin"] = (rng.random((n, 3), dtype=np.float32) * np.float32(2.0) - np.float32(1.0)) * \
+        np.array([0.9 * half, 0.1 * half, 0.9 * half], np.float32) + np.array([0.0, 0.6 * half, 0.0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["tmax"] = np.float32(3.4028235e38)
+    order = bvh.export()["order"]
+    a, _ = scene.trace_rays(rays, mode=api.MODE_STRICT_F32)
+    b, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
+    assert (a["tri_pos"] >= 0).mean() > 0.5
+    assert int(a["tri_pos"].max()) > (1 << 23)          # positions use the upper half of the 24-bit field
+    # oracle on every 40th ray
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    sub = rays[::40]
+    r6, tmax = rays6(sub)
+    ref = osc.trace_rays(r6, tmax)
+    assert np.array_equal(a["tri_pos"][::40], ref["tri"])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(a[f][::40].view(np.uint32), ref[f].view(np.uint32)), f
+    counts = classify_fast_differences(oracle, sc["verts"], order, rays, b, a["tri_pos"], a["t"])
+    record_parity_counts("config4_scene_2M_incoherent_rays_fast_vs_strict", counts)
+    assert counts["differing"] <= 60, counts
+    same = a["tri_pos"] == b["tri_pos"]
+    assert np.array_equal(a["t"][same].view(np.uint32), b["t"][same].view(np.uint32))
+    # geometric check without the oracle: (t, u, v) reproduces the hit point inside the triangle
+    v = sc["verts"].reshape(-1, 3, 3)
+    ok = b["tri_pos"] >= 0
+    h = b[ok]
+    tri = v[order[h["tri_pos"]]].astype(np.float64)
+    u, w_ = h["u"].astype(np.float64)[:, None], h["v"].astype(np.float64)[:, None]
+    on_tri = tri[:, 0] + u * (tri[:, 1] - tri[:, 0]) + w_ * (tri[:, 2] - tri[:, 0])
+    on_ray = rays["origin"][ok].astype(np.float64) + rays["dir"][ok].astype(np.float64) * h["t"].astype(np.float64)[:, None]
+    err = np.abs(on_tri - on_ray).max(axis=1)
+    assert np.quantile(err, 0.999) < 5e-3 and err.max() < 0.2, (np.quantile(err, 0.999), err.max())
+
+
+def test_cfg4_frame_tiles_fast_vs_strict(room_10m):
+    """A band of 64 tiles (two tile rows through the middle of the frame, 2 M
+    pixels) rendered in one call in both modes: pixels that differ are counted
+    and few, two runs of the ordered mode give the same bytes, the tile-linear
+    pixel indexing of a many-tile call equals per-tile calls."""
+    import torch
+    sc, _mesh, _bvh, scene = room_10m
+    tl = scenes.tiles(W, H, GRID)
+    band = tl[15 * GRID:17 * GRID]
+    px = sum(t[3] * t[4] for t in band)
+    stream = torch.cuda.current_stream().cuda_stream
+    accum = torch.empty((px * 3,), dtype=torch.float32, device="cuda")
+
+    def render(mode, group):
+        n = sum(t[3] * t[4] for t in group)
+        rgba = torch.zeros((n * 4,), dtype=torch.uint8, device="cuda")
+        st = scene.render_tiles_device([api.pass_from_dict(_pass_dict(sc, t)) for t in group],
+                                       accum.data_ptr(), rgba.data_ptr(), mode=mode, stream=stream,
+                                       want_stats=True)
+        torch.cuda.synchronize()
+        return rgba.cpu().numpy().reshape(n, 4), st["rays"]
+
+    strict, rays_s = render(api.MODE_STRICT_F32, band)
+    fast_a, rays_f = render(api.MODE_FAST_F32, band)
+    fast_b, rays_f2 = render(api.MODE_FAST_F32, band)
+    assert np.array_equal(fast_a, fast_b) and rays_f == rays_f2
+    differ = int((fast_a != strict).any(axis=1).sum())
+    record_parity_counts("config4_64_tiles_1spp_fast_vs_strict", {
+        "pixels": int(px), "pixels_differing": differ, "rays_strict": int(rays_s), "rays_fast": int(rays_f),
+        "ray_count_delta": int(rays_f - rays_s)})
+    assert differ <= px // 1000, differ
+    assert abs(rays_f - rays_s) <= px // 1000
+    # per-tile calls of three tiles of the band give the bytes of the batched call
+    off = 0
+    for i, t in enumerate(band):
+        n = t[3] * t[4]
+        if i in (0, 33, 63):
+            one, _ = render(api.MODE_STRICT_F32, [t])
+            assert np.array_equal(one, strict[off:off + n]), i
+        off += n
+
+
+@pytest.mark.parametrize("n_tris,linked", [((1 << 24) - 64, 1), ((1 << 24) + 64, 0)])
+def test_node_view_on_both_sides_of_the_24_bit_limit(product_lib, oracle, gpu_device, n_tris, linked):
+    """The linked reference-order view packs (count << 24 | first triangle): a
+    scene with triangle positions at or beyond 2^24 falls back to the plain
+    preorder array, and the ordered view (24-bit positions as well) is not
+    built, so the ordered mode runs the reference order.  Both sides of the limit
+    must give the oracle's hits bit for bit."""
+    sc = scenes.soup(n_tris, seed=0x5EED0001, extent=4.0, size=0.01)
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 8, 48)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    info = scene.info()
+    assert info["linked_view"] == linked
+    assert info["ordered_view"] == linked
+    rays = np.zeros(200_000, api.RAY_DTYPE)
+    rng = np.random.default_rng(3)
+    rays["origin"] = (rng.random((len(rays), 3), dtype=np.float32) * 2 - 1) * np.float32(4.0)
+    d = rng.normal(size=(len(rays), 3)).astype(np.float32)
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["tmax"] = np.float32(3.4028235e38)
+    a, _ = scene.trace_rays(rays, mode=api.MODE_STRICT_F32)
+    b, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    r6, tmax = rays6(rays[::10])
+    ref = osc.trace_rays(r6, tmax)
+    assert np.array_equal(a["tri_pos"][::10], ref["tri"])
+    assert np.array_equal(a["t"][::10].view(np.uint32), ref["t"].view(np.uint32))
+    assert (a["tri_pos"] >= 0).mean() > 0.05
+    assert int(a["tri_pos"].max()) > (1 << 23)
+    if linked:
+        counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, b, a["tri_pos"], a["t"])
+        assert counts["differing"] <= 10, counts
+    else:
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))      # same kernel

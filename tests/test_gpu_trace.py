@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from raytracer_amd import api, scenes
-from util import cornell, oracle_scene, product_mesh, random_rays, rays6
+from util import (classify_fast_differences, cornell, oracle_scene, product_mesh, random_rays, rays6,
+                  record_parity_counts)
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +57,7 @@ def test_primary_rays_config1_shape(soup20k):
     ref64 = osc.trace_rays(r6, tmax, mode=1)
     _check(hits64, ref64)
     grazing = int((hits64["tri_pos"] != ref32["tri"]).sum())
+    record_parity_counts("soup20k_480x270_primary_fp64_vs_f32_oracle", {"rays": int(len(rays)), "differing": grazing})
     assert grazing <= 0.001 * len(rays), grazing
     same = hits64["tri_pos"] == ref32["tri"]
     hit = same & (ref32["tri"] >= 0)
@@ -181,8 +183,8 @@ def _emul_fast(emul, bvh, rays):
     return hits, cnt
 
 
-def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul):
-    _, _, bvh, scene, osc = soup20k
+def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul, oracle):
+    sc, _, bvh, scene, osc = soup20k
     rays = random_rays(300000, seed=9)
     rays["tmax"][::7] = np.float32(0.9)
     hits, st = scene.trace_rays(rays, mode=api.MODE_FAST_F32, counters=True)
@@ -191,8 +193,9 @@ def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul):
     assert [st["rays"], st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]] == cnt.tolist()
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax, counters=True)
-    mismatch = int((hits["tri_pos"] != ref["tri"]).sum())
-    assert mismatch <= 3, mismatch
+    counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
+    record_parity_counts("soup20k_300k_incoherent_rays_fast_vs_oracle", counts)
+    assert counts["differing"] <= 3, counts
     same = hits["tri_pos"] == ref["tri"]
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
     c = ref["counters"]
@@ -223,8 +226,9 @@ def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
     hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax)
-    mismatch = int((hits["tri_pos"] != ref["tri"]).sum())
-    assert mismatch <= 1e-4 * len(rays), mismatch
+    counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
+    record_parity_counts("room6k_axis_aligned_fast_vs_oracle", counts)
+    assert counts["differing"] <= 1e-4 * len(rays), counts
     same = (hits["tri_pos"] == ref["tri"])
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
     assert (hits["tri_pos"] >= 0).mean() > 0.5
@@ -242,7 +246,8 @@ def test_fast_mode_deep_and_degenerate_trees(product_lib, oracle, gpu_device):
         hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
         r6, tmax = rays6(rays)
         ref = osc.trace_rays(r6, tmax)
-        assert int((hits["tri_pos"] != ref["tri"]).sum()) <= 2
+        counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
+        assert counts["differing"] <= 2, counts
         assert (hits["tri_pos"] >= 0).sum() > 0
 
 
@@ -268,6 +273,9 @@ def test_fast_mode_at_extreme_scales(product_lib, oracle, gpu_device, emul, scal
     assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax)
+    counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"],
+                                       degenerate_ok=True)
+    record_parity_counts(f"soup6k_scale_{scale:g}_offset_{offset:g}_fast_vs_oracle", counts)
     differ = hits["tri_pos"] != ref["tri"]
     degenerate = np.zeros(len(rays), bool)
     degenerate[::9] = True

@@ -95,3 +95,81 @@ def struct_copy(src, cls):
     dst = cls()
     C.memmove(C.byref(dst), C.byref(src), C.sizeof(cls))
     return dst
+
+
+# ---------------------------------------------------------------------------
+# Ordered traversal (fast mode) against the reference order: every differing
+# ray is put into a class, and anything outside the permitted classes fails.
+# ---------------------------------------------------------------------------
+def classify_fast_differences(O, verts, order, rays, fast, ref_tri, ref_t, degenerate_ok=False):
+    """`fast`: HIT_DTYPE array of the ordered mode; ref_tri/ref_t: the reference
+    order's hit positions and distances (oracle, or the bit-exact mode).
+    Permitted classes for a ray whose hit id differs:
+      closer_hit   the ordered mode reports a triangle that the oracle's own
+                   triangle test (triangle.go:78-103 + the back-face cull of
+                   bvh.go:121) accepts at 0 < t < t_ref with bit-identical
+                   t, u, v: the reference's box test pruned it (its box test
+                   is done in float32 on the exact boxes, the ordered mode's on
+                   boxes that contain them)
+      equal_t      the same with t == t_ref and an EARLIER array position
+    and, only with degenerate_ok (rays with a zero or denormal direction
+    component, whose infinite inverse direction makes NaN slabs that the two
+    slab forms treat differently):
+      nan_slab     any other outcome on such a ray
+    Returns the class counts."""
+    verts = np.asarray(verts, np.float32).reshape(-1, 3, 3)
+    counts = {"rays": int(len(rays)), "differing": 0, "closer_hit": 0, "equal_t": 0, "nan_slab": 0}
+    differ = np.nonzero(fast["tri_pos"] != ref_tri)[0]
+    counts["differing"] = int(len(differ))
+    for i in differ:
+        o, d = rays["origin"][i], rays["dir"][i]
+        pf, pr = int(fast["tri_pos"][i]), int(ref_tri[i])
+        degenerate = bool((np.abs(d) < np.float32(1.1754944e-38)).any())
+        ok = False
+        if pf >= 0:
+            v = verts[order[pf]]
+            n = np.zeros(3, np.float32)
+            O.lib().orc_tri_normal(*[x.ctypes.data_as(C.c_void_p) for x in
+                                     (np.ascontiguousarray(v[0]), np.ascontiguousarray(v[1]),
+                                      np.ascontiguousarray(v[2]), n)])
+            facing = not ((n[0] * d[0] + n[1] * d[1]) + n[2] * d[2] > 0)     # float32, in the reference's order
+            t, u, w = O.tri_intersect(v[0], v[1], v[2], o, d)
+            t32, u32, w32 = np.float32(t), np.float32(u), np.float32(w)
+            same_numbers = (t32.view(np.uint32) == fast["t"][i].view(np.uint32)
+                            and u32.view(np.uint32) == fast["u"][i].view(np.uint32)
+                            and w32.view(np.uint32) == fast["v"][i].view(np.uint32))
+            if facing and t32 > 0 and same_numbers:
+                if t32 < ref_t[i]:
+                    counts["closer_hit"] += 1
+                    ok = True
+                elif t32 == ref_t[i] and (pr < 0 or pf < pr):
+                    counts["equal_t"] += 1
+                    ok = True
+        if not ok:
+            assert degenerate_ok and degenerate, \
+                f"ray {i}: ordered mode reports triangle {pf} (t {fast['t'][i]!r}), reference order {pr} " \
+                f"(t {ref_t[i]!r}): not a hit the reference's box test pruned"
+            counts["nan_slab"] += 1
+    return counts
+
+
+def record_parity_counts(name, counts):
+    """Merge one test's measured counts into gpurun_out/parity_counts.json (the
+    file travels back from the GPU box; the round's copy is kept under
+    profiles/)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "parity_counts.json")
+    data = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                data = json.load(f)
+        except ValueError:
+            data = {}
+    data[name] = counts
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+    print(f"[parity counts] {name}: {counts}")
