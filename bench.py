@@ -73,9 +73,9 @@ def parse_args():
                          "share one GPU) is for rehearsing the multi-rank path on a 1-GPU box")
     ap.add_argument("--dynamic", action="store_true",
                     help="ranks pull tiles from a shared counter instead of the static block-cyclic deal")
-    ap.add_argument("--chunk", type=int, default=8, help="tiles taken per pull with --dynamic")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="tiles taken per pull with --dynamic (0 = enough for about 32 M camera samples per call)")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
-    ap.add_argument("--opt", default="", help="scene options name=value,... (experiments; see rt_scene_set_option)")
     ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
     ap.add_argument("--pretend-world", type=int, default=0,
                     help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
@@ -234,9 +234,6 @@ def main():
     setup_s = time.perf_counter() - t0
     if args.tune:
         scene.set_tuning(*[int(x) for x in args.tune.split(",")])
-    for kv in filter(None, args.opt.split(",")):
-        k, v = kv.split("=")
-        scene.set_option(k, int(v))
     if args.max_paths:
         scene.set_max_paths(args.max_paths)
     tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
@@ -256,8 +253,8 @@ def main():
     frame_host = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8) if coll_dev == "cpu" else None
     queue = None
     if args.dynamic and world > 1:
-        queue = tiles.TileQueue(dist.distributed_c10d._get_default_store(), len(tile_list),
-                                chunk=args.chunk)
+        chunk = args.chunk or tiles.pull_chunk(len(tile_list), world, tile_list[0][3] * tile_list[0][4] * args.spp)
+        queue = tiles.TileQueue(dist.distributed_c10d._get_default_store(), len(tile_list), chunk=chunk)
 
     def make_pass(tile, spp, seed):
         tid, x, y, w, h = tile
@@ -268,19 +265,19 @@ def main():
 
     pass_cache = {}
 
-    def render_tiles(group, step):
+    def render_tiles(group, step, off_px=0):
         """One call for a whole group of tiles: one ray queue per path depth for
         the group, so small tiles still fill the GPU.  The pass records of a group
         are built once; a new frame only changes the per-tile seeds (the frontend
         sends base seed + task id, Renderer.js:423)."""
-        key = group[0][0], len(group)
+        key = group[0][0], len(group)   # (first tile id, count) names a group: pulls are contiguous id ranges
         arr = pass_cache.get(key)
         if arr is None:
             arr = pass_cache[key] = api.pass_array([make_pass(t, args.spp, 0) for t in group])
         for i, t in enumerate(group):
             arr[i].rng_seed = 1 + 1000 * step + t[0]
-        return scene.render_tiles_device(arr, d_accum.data_ptr(), d_tiles.data_ptr(), mode=mode,
-                                         stream=stream, want_stats=True)
+        return scene.render_tiles_device(arr, d_accum.data_ptr() + off_px * 12, d_tiles.data_ptr() + off_px * 4,
+                                         mode=mode, stream=stream, want_stats=True)
 
     def run_step(step, collect):
         rays, kernel_ms, launches = 0, 0.0, 0
@@ -293,24 +290,26 @@ def main():
                 else:
                     tiles.gather_static(d_tiles.cpu(), tile_list, world, rank, frame_host)
         else:
-            # pull-based: take the next chunk of tiles until the list is empty
+            # pull-based: take the next chunk of tiles until the list is empty; the images of
+            # the chunks line up back to back in this rank's tile buffer
             queue.reset(epoch=step)
-            frame.zero_()
+            my_ids, off_px = [], 0
             while True:
                 got = queue.pull()
                 if not got:
                     break
                 group = [tile_list[i] for i in got]
-                st = render_tiles(group, step)
+                st = render_tiles(group, step, off_px)
                 rays += st["rays"]
                 kernel_ms += st["kernel_ms"]
                 launches += st["kernel_launches"]
-                off = 0
-                for (tid, x, y, w, h) in group:
-                    frame[y:y + h, x:x + w] = d_tiles[off:off + w * h * 4].view(h, w, 4)
-                    off += w * h * 4
+                my_ids += got
+                off_px += sum(t[3] * t[4] for t in group)
             if not args.no_gather:
-                tiles.reduce_dynamic(frame if coll_dev == "cuda" else frame.cpu(), world, rank)
+                if coll_dev == "cuda":
+                    tiles.gather_dynamic(d_tiles, my_ids, tile_list, world, rank, frame)
+                else:
+                    tiles.gather_dynamic(d_tiles.cpu(), my_ids, tile_list, world, rank, frame_host)
         if collect:
             collect["rays"] += rays
             collect["kernel_ms"] += kernel_ms
@@ -364,19 +363,74 @@ def main():
         # what the library holds in HBM for the scene: triangle records, both tree views, shading words, tables
         scene_mb = scene.info()["total_device_bytes"] / 1e6
         value = total_rays / elapsed / 1e6
-        # roofline of the traversal kernel: this rank's algorithmic bytes over the
-        # time its traversal launches took (HIP events on the launch stream)
+        # roofline of the traversal kernel, measured on this rank: rays over the time its
+        # traversal launches took (HIP events on the launch stream, inside the timed region)
         rank_rays = float(acc["rays"])
-        achieved = rank_rays * bpr / (acc["kernel_ms"] * 1e-3) / 1e9 if acc["kernel_ms"] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.mode == "fast":   # the counters were collected on the ordered kernel
-            # measured per ray on shorter launches of the same workload (a counter pass renders a few
-            # samples per pixel); per launch of THIS run, like `achieved`: x this run's rays per launch
-            with open(tpath) as f:
-                per_ray = json.load(f).get(args.workload, {}).get("hbm_bytes_per_ray")
-            if per_ray and acc["launches"]:
-                traffic = round(per_ray * rank_rays / acc["launches"], 1)
+        trav_s = acc["kernel_ms"] * 1e-3
+        rays_per_s = rank_rays / trav_s if trav_s > 0 else 0.0
+        algorithmic = rays_per_s * bpr / 1e9                       # GB/s of counted record + triangle fetches
+        kernel = {"fast": "k_trace_fast", "strict": "k_trace_ref<float>", "fp64": "k_trace_ref<double>"}[args.mode]
+
+        def profile_entry(name):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                return None
+            with open(path) as f:
+                return json.load(f).get(args.workload, {}).get(args.mode)
+
+        # fabric bytes per ray and VALU lane-instructions per ray are counter measurements of this
+        # kernel on this workload, taken in separate rocprofv3 --pmc runs and kept under profiles/
+        fabric = profile_entry("r02_traffic.json")
+        valu = profile_entry("r02_valu_per_ray.json")
+        traffic = traffic_src = None
+        if fabric and acc["launches"]:
+            traffic = round(fabric["hbm_bytes_per_ray"] * rank_rays / acc["launches"], 1)
+            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per ray) x this run's rays per launch"
+        hbm_rate = fabric["hbm_bytes_per_ray"] * rays_per_s / 1e9 if fabric else None
+        resident = scene_mb < INFINITY_CACHE_MB
+        roof = {"kernel": kernel, "traffic": traffic, "traffic_source": traffic_src,
+                "rays_per_s_in_kernel": round(rays_per_s, 1),
+                "bytes_per_ray": round(bpr, 1), "bytes_per_ray_reference_order": round(bpr_ref, 1),
+                "algorithmic_GBps": round(algorithmic, 1),
+                "algorithmic_GBps_reference_order": round(algorithmic * bpr_ref / bpr, 1) if bpr > 0 else 0.0,
+                "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
+                "kernel_launches_per_step": acc["launches"] // max(args.steps, 1),
+                "kernel_avg_launch_ms": round(acc["kernel_ms"] / max(acc["launches"], 1), 4),
+                "scene_mb": round(scene_mb, 1)}
+        if resident:
+            # the scene lives in L2 / Infinity Cache: HBM is not the ceiling.  The kernel is bound by
+            # VALU issue (profiles/): achieved = active lane-instructions per ray (SQ_THREAD_CYCLES_VALU
+            # / rays) x rays/s against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+            lane_per_ray = valu["lane_inst_per_ray"] if valu else None
+            ach = lane_per_ray * rays_per_s / 1e12 if lane_per_ray else None
+            roof.update({"bound": "valu", "unit": "Tlane-inst/s", "peak": round(VALU_PEAK_TLANE, 2),
+                         "achieved": round(ach, 3) if ach else None,
+                         "frac": round(ach / VALU_PEAK_TLANE, 4) if ach else None,
+                         "lane_inst_per_ray": lane_per_ray,
+                         "lane_inst_source": "profiles/r02_valu_per_ray.json (tools/pmc_valu.py)" if valu else None})
+            # beside it: the gather ceiling of the cache hierarchy for tables of this scene's size
+            info = scene.info()
+            recs = {}
+            for label, nbytes in (("ordered_view", info["ordered_bytes"]),
+                                  ("ordered_view_plus_triangles", info["ordered_bytes"] + info["tri_bytes"])):
+                if nbytes:
+                    recs[label] = {"table_mb": round(nbytes / 1e6, 1),
+                                   "records_per_s": round(api.gather_probe(local_rank, nbytes), 1)}
+            kernel_recs = (nodes_per_ray + 0.75 * tris_per_ray) * rays_per_s     # a triangle record is 48 of 64 bytes
+            ceiling = recs.get("ordered_view_plus_triangles", {}).get("records_per_s")
+            roof["l2_mall"] = {"gather_ceiling": recs, "kernel_records_per_s": round(kernel_recs, 1),
+                               "frac": round(kernel_recs / ceiling, 4) if ceiling else None,
+                               "note": "rt_gather_probe: every lane chases random 64-byte records through a table of "
+                                       "the given size (measured by this run outside its timed region)"}
+            roof["hbm"] = {"achieved": round(hbm_rate, 1) if hbm_rate else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None,
+                           "note": "measured fabric bytes, not algorithmic ones"}
+        else:
+            # beyond the Infinity Cache: HBM, priced at the MEASURED fabric bytes
+            roof.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                         "achieved": round(hbm_rate, 1) if hbm_rate else None,
+                         "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None})
         out = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -391,27 +445,7 @@ def main():
                        "tile_assignment": "dynamic pull queue" if queue is not None else "block-cyclic",
                        "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
                        "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": {"fast": "k_trace_fast", "strict": "k_trace_ref<float>",
-                                                   "fp64": "k_trace_ref<double>"}[args.mode],
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "bytes_per_ray": round(bpr, 1),
-                         "bytes_per_ray_reference_order": round(bpr_ref, 1),
-                         "achieved_reference_order": round(achieved * bpr_ref / bpr, 1) if bpr > 0 else 0.0,
-                         "nodes_per_ray": round(nodes_per_ray, 2),
-                         "tris_per_ray": round(tris_per_ray, 2),
-                         "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
-                         "kernel_launches_per_step": acc["launches"] // max(args.steps, 1),
-                         "kernel_avg_launch_ms": round(acc["kernel_ms"] / max(acc["launches"], 1), 4),
-                         "scene_mb": round(scene_mb, 1),
-                         "note": "achieved = rays x bytes_per_ray (this kernel's own counted record and "
-                                 "triangle fetches) / traversal-launch time; achieved_reference_order prices "
-                                 "the same rays at what the reference's left-first binary walk fetches. A scene below 256 MB is "
-                                 "served from L2 / Infinity Cache, so the algorithmic rate can exceed the "
-                                 "HBM peak; traffic = measured fabric bytes per ray of this workload x this run's rays per launch "
-                                 "(rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/traffic.json). Random 64-byte record gathers top out "
-                                 "at 6.5 TB/s on a 10 MB table, 3.8 TB/s on 64 MB and 3.5 TB/s on 1 GB "
-                                 "on this GPU (tools/ubench/gather.hip)"},
+            "roofline": roof,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(sc, bvh.export(), tables, wl, args, tile_list)

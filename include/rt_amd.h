@@ -212,12 +212,6 @@ uint64_t rt_workspace_bytes_per_path(int32_t light_sample_rays, int32_t bounce_l
  * do not depend on them. */
 rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t refill_below,
                               int32_t blocks_per_cu, int32_t descend_min, int32_t leaf_min);
-/* Further scheduling options of the ordered traversal, by name (results do not
- * depend on them): "pair" 0/1 = one ray per lane (k_trace_fast) or two
- * (k_trace_pair), "pair_stack" 4/6/8 = LDS stack entries per ray of the latter,
- * "swap_desc" / "swap_leaf" 0..64 = a lane exchanges its two rays once fewer
- * lanes than this can take part in the descent / leaf phase. */
-rt_status rt_scene_set_option(rt_scene *scene, const char *name, int32_t value);
 /* When enabled, render calls that return rt_stats run the counting variant of
  * the traversal kernel and fill nodes_visited / box_tests / tris_fetched /
  * tris_tested (slower; for the roofline byte model, not for timed runs). */

@@ -100,7 +100,6 @@ SIGNATURES = {
     "rt_scene_set_workspace_limit": (C.c_int32, [vp, C.c_uint64]),
     "rt_workspace_bytes_per_path": (C.c_uint64, [C.c_int32, C.c_int32]),
     "rt_scene_set_tuning": (C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "rt_scene_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int32]),
     "rt_scene_set_counters": (C.c_int32, [vp, C.c_int32]),
     "rt_scene_destroy": (None, [vp]),
     "rt_trace_rays": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, C.c_int32, C.POINTER(Stats)]),

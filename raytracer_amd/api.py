@@ -250,9 +250,6 @@ class Scene:
         check(lib().rt_scene_set_tuning(self._h, stack_entries, refill_below, blocks_per_cu, descend_min,
                                         leaf_min))
 
-    def set_option(self, name, value):
-        check(lib().rt_scene_set_option(self._h, name.encode(), int(value)))
-
     def set_counters(self, enabled):
         check(lib().rt_scene_set_counters(self._h, int(enabled)))
 

@@ -210,19 +210,6 @@ rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t re
     return RT_OK;
 }
 
-rt_status rt_scene_set_option(rt_scene *scene, const char *name, int32_t value) {
-    if (!scene || !scene->impl || !name) return fail(RT_ERR_INVALID, "NULL argument");
-    rt::Scene &sc = *scene->impl;
-    const std::string key(name);
-    if (key == "pair" && (value == 0 || value == 1)) sc.tune_pair = value;
-    else if (key == "pair_stack" && (value == 4 || value == 6 || value == 8)) sc.tune_pair_stack = value;
-    else if (key == "swap_desc" && value >= 0 && value <= 64) sc.tune_swap_desc = value;
-    else if (key == "swap_leaf" && value >= 0 && value <= 64) sc.tune_swap_leaf = value;
-    else if (key == "leaf_start" && value >= 1 && value <= 65) sc.tune_leaf_start = value;
-    else return fail(RT_ERR_INVALID, "unknown option or value out of range: " + key);
-    return RT_OK;
-}
-
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (max_paths < 64 || max_paths > ((uint64_t)1 << 28))

@@ -92,11 +92,6 @@ struct Scene {
     int tune_blocks_per_cu = 8;   // persistent grid size
     int tune_leaf_min = 0;        // leave the leaf phase below this many lanes in a leaf (0 = per-kernel default)
     int tune_descend_min = 0;     // leave the descent phase below this many descending lanes (0 = per-kernel default)
-    int tune_pair = 0;            // ordered mode: two rays per lane (k_trace_pair) instead of one
-    int tune_pair_stack = 8;      // its LDS stack entries per ray (4, 6 or 8)
-    int tune_swap_desc = 48;      // exchange a lane's rays once fewer lanes than this can descend ...
-    int tune_swap_leaf = 32;      // ... or hold a leaf
-    int tune_leaf_start = 65;     // the descent phase also ends once this many lanes hold a leaf ray (65: never)
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;

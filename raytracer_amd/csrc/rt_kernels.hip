@@ -539,280 +539,6 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 }
 
 // ---------------------------------------------------------------------------
-// Ordered traversal with TWO rays per lane.  The step code is k_trace_fast's;
-// what changes is who runs it.  With one ray per lane a lane whose ray waits in
-// a leaf idles through the descent phase and the other way round (lane
-// utilisation 69 % / 46 % of the two phases).  Here every lane owns a second
-// ray whose state sits in registers beside the current one: when the lanes
-// that can take part in the running phase fall below `swap_below`, every lane
-// whose current ray cannot take part but whose other ray can exchanges the
-// two (registers only; each ray keeps its own stack and parked values, picked
-// by the lane's `cur` bit), and the phase goes on with a full wave.  A ray's
-// status is kept in its `where` word: a record index, a leaf reference,
-// kRefDone (finished, result not yet written) or kRefFree (no ray).
-// ---------------------------------------------------------------------------
-constexpr uint32_t kRefFree = 0xFFFFFFFEu;   // a leaf reference that is never built (see kFastMaxTris)
-
-template <bool COUNT, int kStackLds>
-__global__ void __launch_bounds__(256)
-k_trace_pair(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
-             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters, int refill_below, int descend_min, int leaf_min,
-             int swap_desc, int swap_leaf, int leaf_start) {
-    constexpr int kStackSpill = kStackTotal - kStackLds;
-    __shared__ uint2 lds_stack[4 * 2 * kStackLds * 64];   // [wave][ray of the lane][entry][lane]
-    __shared__ float park[2 * 6 * 256];                   // [ray of the lane][value][thread]
-    const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t lane = lane_id();
-    uint2 *const stack_base = lds_stack + (threadIdx.x >> 6) * (2 * kStackLds * 64) + lane;
-    float *const park_base = park + threadIdx.x;
-    uint2 spill[2 * kStackSpill];
-    RayFeed feed;
-    // the current ray: origin, inverse direction, closest hit, where it stands, stack height
-    float r_ox = 0, r_oy = 0, r_oz = 0, r_ix = 0, r_iy = 0, r_iz = 0, h_t = 0;
-    int32_t h_pos = -1, sp = 0;
-    uint32_t where = kRefFree;
-    // the lane's other ray
-    float q_ox = 0, q_oy = 0, q_oz = 0, q_ix = 0, q_iy = 0, q_iz = 0, q_t = 0;
-    int32_t q_pos = -1, q_sp = 0;
-    uint32_t q_where = kRefFree;
-    uint32_t cur = 0;            // which of the lane's two stack / park areas the current ray owns
-    uint2 *my_stack = stack_base;
-    float *my_park = park_base;
-    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
-
-    auto descends = [](uint32_t w) { return (w & kLeafBit) == 0; };
-    auto in_leaf = [](uint32_t w) { return (w & kLeafBit) != 0 && w < kRefFree; };
-    auto exchange = [&](bool c) {
-        if (c) {
-            float f;
-            f = r_ox; r_ox = q_ox; q_ox = f;
-            f = r_oy; r_oy = q_oy; q_oy = f;
-            f = r_oz; r_oz = q_oz; q_oz = f;
-            f = r_ix; r_ix = q_ix; q_ix = f;
-            f = r_iy; r_iy = q_iy; q_iy = f;
-            f = r_iz; r_iz = q_iz; q_iz = f;
-            f = h_t; h_t = q_t; q_t = f;
-            int32_t i;
-            i = h_pos; h_pos = q_pos; q_pos = i;
-            i = sp; sp = q_sp; q_sp = i;
-            uint32_t u = where; where = q_where; q_where = u;
-            cur ^= 1u;
-            my_stack = stack_base + cur * (kStackLds * 64);
-            my_park = park_base + cur * (6 * 256);
-        }
-    };
-    auto push = [&](uint32_t ref, float tn) {
-        const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
-        if (sp < kStackLds) my_stack[sp * 64] = e;
-        else if (sp < kStackTotal) spill[cur * kStackSpill + (sp - kStackLds)] = e;
-        sp++;
-    };
-    // Next stacked entry of the current ray that can still hold a closer hit; the
-    // ray is finished when there is none.
-    auto pop_next = [&]() {
-        while (sp > 0) {
-            sp--;
-            uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
-            asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
-            if (sp >= kStackLds) e = spill[cur * kStackSpill + (sp - kStackLds)];
-            if (i2f((int32_t)e.y) < h_t) {
-                where = e.x;
-                return;
-            }
-        }
-        where = kRefDone;
-    };
-    auto emit = [&](int32_t pos, float t, const float *pk) {
-        f4 out;
-        out.x = i2f(pos);
-        out.y = t;
-        out.z = pk[0 * 256];
-        out.w = pk[1 * 256];
-        const int32_t idx = f2i(pk[2 * 256]);
-        *reinterpret_cast<f4 *>(hits + idx) = out;
-    };
-
-    for (;;) {
-        // retire finished rays, refill free places (both rays of a lane)
-        float *other_park = park_base + (cur ^ 1u) * (6 * 256);
-        if (where == kRefDone) {
-            emit(h_pos, h_t, my_park);
-            where = kRefFree;
-        }
-        if (q_where == kRefDone) {
-            emit(q_pos, q_t, other_park);
-            q_where = kRefFree;
-        }
-        const uint64_t free0 = __ballot(where == kRefFree), free1 = __ballot(q_where == kRefFree);
-        if (!(feed.exhausted && feed.pos >= feed.end) &&
-            128 - (int)__popcll(free0) - (int)__popcll(free1) < refill_below) {
-            int32_t mine = feed_take(feed, next, n, free0);
-            if (mine >= 0) {
-                const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
-                const f4 a = rp[0], b = rp[1];
-                r_ox = a.x; r_oy = a.y; r_oz = a.z;
-                r_ix = 1.0f / b.x; r_iy = 1.0f / b.y; r_iz = 1.0f / b.z;   // ray.go:33-37
-                h_t = a.w;
-                h_pos = -1;
-                my_park[0 * 256] = 0.0f;
-                my_park[1 * 256] = 0.0f;
-                my_park[2 * 256] = i2f(mine);
-                my_park[3 * 256] = b.x;
-                my_park[4 * 256] = b.y;
-                my_park[5 * 256] = b.z;
-                sp = 0;
-                where = s.fast_root;
-            }
-            mine = feed_take(feed, next, n, free1);
-            if (mine >= 0) {
-                const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
-                const f4 a = rp[0], b = rp[1];
-                q_ox = a.x; q_oy = a.y; q_oz = a.z;
-                q_ix = 1.0f / b.x; q_iy = 1.0f / b.y; q_iz = 1.0f / b.z;
-                q_t = a.w;
-                q_pos = -1;
-                other_park[0 * 256] = 0.0f;
-                other_park[1 * 256] = 0.0f;
-                other_park[2 * 256] = i2f(mine);
-                other_park[3 * 256] = b.x;
-                other_park[4 * 256] = b.y;
-                other_park[5 * 256] = b.z;
-                q_sp = 0;
-                q_where = s.fast_root;
-            }
-        }
-        if (__ballot(where != kRefFree || q_where != kRefFree) == 0) {
-            if (feed.exhausted && feed.pos >= feed.end) break;
-            continue;   // the chunk ran dry in the middle of a refill: take the next one
-        }
-
-        // phase A: lanes whose current ray stands on an interior record descend
-        for (;;) {
-            uint64_t m_desc = __ballot(descends(where));
-            if ((int)__popcll(m_desc) < swap_desc) {
-                const bool sw = !descends(where) && descends(q_where);
-                if (__ballot(sw) != 0) {
-                    exchange(sw);
-                    m_desc = __ballot(descends(where));
-                }
-            }
-            if (m_desc == 0) break;
-            {
-                const uint64_t m_anyleaf = __ballot(in_leaf(where) || in_leaf(q_where));
-                if ((int)__popcll(m_desc) < descend_min && m_anyleaf != 0) break;
-                if ((int)__popcll(m_anyleaf) >= leaf_start) break;
-            }
-            if (!descends(where)) continue;
-            const f4 *q = s.wide + 4 * (size_t)where;
-            const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
-            const f2 fo_x{q0.x, q0.x}, fo_y{q0.y, q0.y}, fo_z{q0.z, q0.z};
-            const f2 fs_x{q0.w, q0.w}, fs_y{q1.x, q1.x}, fs_z{q1.y, q1.y};
-            const bool nx = r_ix < 0, ny = r_iy < 0, nz = r_iz < 0;
-            const uint32_t lox = (uint32_t)f2i(q1.z), loy = (uint32_t)f2i(q1.w), loz = (uint32_t)f2i(q2.x);
-            const uint32_t hix = (uint32_t)f2i(q2.y), hiy = (uint32_t)f2i(q2.z), hiz = (uint32_t)f2i(q2.w);
-            const uint32_t plx = nx ? hix : lox, ply = ny ? hiy : loy, plz = nz ? hiz : loz;   // near
-            const uint32_t phx = nx ? lox : hix, phy = ny ? loy : hiy, phz = nz ? loz : hiz;   // far
-            const f2 ox{r_ox, r_ox}, oy{r_oy, r_oy}, oz{r_oz, r_oz};
-            const f2 ix{r_ix, r_ix}, iy{r_iy, r_iy}, iz{r_iz, r_iz};
-            float key[4];
-            uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
-#define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
-#define RT_SLAB(k)                                                                          \
-            {                                                                               \
-                const f2 bx = __builtin_elementwise_fma(f2{RT_BYTE(plx, k), RT_BYTE(phx, k)}, fs_x, fo_x); \
-                const f2 by = __builtin_elementwise_fma(f2{RT_BYTE(ply, k), RT_BYTE(phy, k)}, fs_y, fo_y); \
-                const f2 bz = __builtin_elementwise_fma(f2{RT_BYTE(plz, k), RT_BYTE(phz, k)}, fs_z, fo_z); \
-                const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
-                const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
-                const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                const bool hit = tn <= tf && tn < h_t && tf > 0 && ref[k] != kLeafBit;      \
-                key[k] = hit ? tn : kF32Inf;                                                \
-            }
-            RT_SLAB(0)
-            RT_SLAB(1)
-            RT_SLAB(2)
-            RT_SLAB(3)
-#undef RT_SLAB
-#undef RT_BYTE
-            wide_sort4(key, ref);
-            if (!(key[0] < kF32Inf)) {
-                pop_next();
-            } else {
-                if (key[3] < kF32Inf) push(ref[3], key[3]);
-                if (key[2] < kF32Inf) push(ref[2], key[2]);
-                if (key[1] < kF32Inf) push(ref[1], key[1]);
-                where = ref[0];
-            }
-        }
-        // phase B: lanes whose current ray holds a leaf test its triangles
-        for (;;) {
-            uint64_t m_leaf = __ballot(in_leaf(where));
-            if ((int)__popcll(m_leaf) < swap_leaf) {
-                const bool sw = !in_leaf(where) && in_leaf(q_where);
-                if (__ballot(sw) != 0) {
-                    exchange(sw);
-                    m_leaf = __ballot(in_leaf(where));
-                }
-            }
-            if (m_leaf == 0) break;
-            if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(__ballot(descends(where) || descends(q_where))) >= descend_min) break;
-            if (!in_leaf(where)) continue;
-            const int32_t tri_i = (int32_t)(where & 0xFFFFFFu), tri_n = (int32_t)((where >> 24) & 0x7Fu);
-            const bool two = tri_n > 1;
-            const f4 *qa = s.tris + 3 * (size_t)tri_i;
-            const f4 *qb = qa + (two ? 3 : 0);
-            const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
-            const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-            if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
-            Ray<float> r;
-            r.ox = r_ox; r.oy = r_oy; r.oz = r_oz;
-            r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
-            r.ix = r_ix; r.iy = r_iy; r.iz = r_iz;
-            Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
-            bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
-            if (COUNT && tested) c_test++;
-            if (two) {
-                tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
-                if (COUNT && tested) c_test++;
-            }
-            if (h.pos != h_pos) {      // a triangle is accepted at most once
-                my_park[0 * 256] = h.u;
-                my_park[1 * 256] = h.v;
-                h_pos = h.pos;
-            }
-            h_t = h.t;
-            if (tri_n <= 2) {
-                pop_next();
-            } else {
-                where = kLeafBit | ((uint32_t)(tri_n - 2) << 24) | (uint32_t)(tri_i + 2);
-            }
-        }
-    }
-    if (COUNT) {
-        c_nodes = wave_sum(c_nodes);
-        c_box = wave_sum(c_box);
-        c_fetch = wave_sum(c_fetch);
-        c_test = wave_sum(c_test);
-        c_wa = wave_sum(c_wa);
-        c_wb = wave_sum(c_wb);
-        c_lb = wave_sum(c_lb);
-        if (lane == 0) {
-            atomicAdd(counters + 5, (unsigned long long)c_wa);
-            atomicAdd(counters + 6, (unsigned long long)c_wb);
-            atomicAdd(counters + 7, (unsigned long long)c_lb);
-            atomicAdd(counters + 1, (unsigned long long)c_nodes);
-            atomicAdd(counters + 2, (unsigned long long)c_box);
-            atomicAdd(counters + 3, (unsigned long long)c_fetch);
-            atomicAdd(counters + 4, (unsigned long long)c_test);
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + 0, (unsigned long long)n);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Path-tracing wavefront kernels
 // ---------------------------------------------------------------------------
 enum : uint32_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
@@ -1369,23 +1095,6 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     case RT_MODE_FAST_F32:
         if (sc.d_wide) {
             const int rb = t_refill;
-            if (sc.tune_pair) {
-                // two rays per lane: the refill threshold counts rays, of 128 per wave
-                const int rb2 = sc.tune_refill > 0 ? 2 * sc.tune_refill : 120;
-                const int sa = sc.tune_swap_desc, sl = sc.tune_swap_leaf;
-#define RT_PAIR(C, N) hipLaunchKernelGGL((k_trace_pair<C, N>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb2, t_desc, t_leaf, sa, sl, sc.tune_leaf_start)
-                if (d_counters) {
-                    RT_PAIR(true, 8);
-                } else {
-                    switch (sc.tune_pair_stack) {
-                    case 4: RT_PAIR(false, 4); break;
-                    case 6: RT_PAIR(false, 6); break;
-                    default: RT_PAIR(false, 8); break;
-                    }
-                }
-#undef RT_PAIR
-                break;
-            }
             if (d_counters) {
                 hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
             } else {

@@ -56,18 +56,23 @@ def _worker(rank, world, port, dynamic, out_path):
             store = dist.distributed_c10d._get_default_store()
             q = tiles.TileQueue(store, len(tile_list), chunk=3)
             q.reset(epoch=0)
-            local = torch.zeros((H, W, 4), dtype=torch.uint8)
             done = torch.zeros(len(tile_list), dtype=torch.int64)
+            buf = torch.zeros(W * H * 4, dtype=torch.uint8)      # a rank may end up with any tile
+            my_ids, off = [], 0
             while True:
                 got = q.pull()
                 if not got:
                     break
                 for i in got:
                     tid, x, y, w, h = tile_list[i]
-                    local[y:y + h, x:x + w] = _fake_render(tile_list[i])
+                    img = _fake_render(tile_list[i]).reshape(-1)
+                    buf[off:off + img.numel()] = img
+                    off += img.numel()
+                    my_ids.append(i)
                     done[i] += 1
                     rays_here += w * h
-            frame = tiles.reduce_dynamic(local, world, rank)
+            frame = torch.zeros((H, W, 4), dtype=torch.uint8) if rank == 0 else None
+            frame = tiles.gather_dynamic(buf, my_ids, tile_list, world, rank, frame)
             dist.all_reduce(done)
             counts = done
         total, = tiles.sum_counters([rays_here], "cpu", world)

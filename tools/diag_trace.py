@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--leaf", type=int, default=8)
     ap.add_argument("--mode", default="fast")
     ap.add_argument("--tune", default="")
-    ap.add_argument("--opt", default="", help="scene options name=value,...")
     args = ap.parse_args()
     import torch
     from raytracer_amd import api, scenes
@@ -31,9 +30,6 @@ def main():
     scene = api.Scene(mesh, bvh, 0)
     if args.tune:
         scene.set_tuning(*[int(x) for x in args.tune.split(",")])
-    for kv in filter(None, args.opt.split(",")):
-        k, v = kv.split("=")
-        scene.set_option(k, int(v))
     W, H = 3840, 2160
     tl = scenes.tiles(W, H, 16)
     px = sum(t[3] * t[4] for t in tl)
