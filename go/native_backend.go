@@ -14,8 +14,9 @@ package main
 #include <stdlib.h>
 #include "rt_backend.h"
 
-extern void goProgress(char *json, void *user);          // exported below
-static void install_progress(rtb_context *c) { rtb_set_progress_callback(c, (rtb_progress_fn)goProgress, NULL); }
+// A file that uses //export may only DECLARE C functions in this preamble;
+// install_progress is defined in progress_glue.go.
+void install_progress(rtb_context *c);
 */
 import "C"
 import (

@@ -92,6 +92,8 @@ def lib():
         L.orc_camera_ray.argtypes = [vp, C.POINTER(Pass), C.c_int32, C.c_int32, C.c_uint64, vp]
         L.orc_render_tile.argtypes = [vp, C.POINTER(Pass), C.c_int32, C.c_int32, C.c_int32,
                                       vp, vp, vp, C.POINTER(Counters)]
+        L.orc_render_progress.restype = C.c_int32
+        L.orc_render_progress.argtypes = [vp, C.POINTER(Pass), C.c_uint64, vp, vp, C.c_int32]
         L.orc_resolve.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]
         L.orc_aabb_intersect.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -282,6 +284,14 @@ class Scene:
         if want_radiance:
             out["radiance"] = rad
         return out
+
+
+def render_progress(scene, p, base_rays=0, max_events=64):
+    """[(progress, rays)] of the "trace" events render() issues (main.go:120-154)."""
+    prog = np.zeros(max_events, np.float32)
+    rays = np.zeros(max_events, np.uint64)
+    n = lib().orc_render_progress(scene._h, C.byref(p), int(base_rays), _ptr(prog), _ptr(rays), max_events)
+    return [(float(prog[i]), int(rays[i])) for i in range(min(n, max_events))]
 
 
 def resolve(accum, divisor, gamma_on, gamma):

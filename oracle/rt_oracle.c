@@ -1192,3 +1192,48 @@ void orc_render_tile(orc_scene *s, const orc_pass *pass, int32_t sample_begin,
                     pass->settings.gamma, rgba);
     if (!accum) free(acc);
 }
+
+/* main.go:117-154: the progress bookkeeping of render() around the same pixel
+ * loop.  Records every ProgressUpdate(progress, "trace", ...) the reference
+ * issues while tracing -- 0.0 first, one whenever the running sample index
+ * passes updateIndex + updateInterval, 1.0 last -- with the value context.Rays
+ * has at that moment (base_rays + rays cast so far).  Returns the number of
+ * events (at most max_events are stored). */
+int32_t orc_render_progress(orc_scene *s, const orc_pass *pass, uint64_t base_rays,
+                            float *progress, uint64_t *rays, int32_t max_events)
+{
+    orc_camera cam;
+    orc_light light;
+    float tl[3], steps[2];
+    orc_counters counters;
+    memset(&counters, 0, sizeof counters);
+    pass_prepare(s, pass, &cam, &light);
+    orc_camera_setup(&cam, pass->total_width < 0 ? 0 : pass->total_width,
+                     pass->total_height < 0 ? 0 : pass->total_height, tl, steps);
+    int32_t n = 0;
+#define ORC_EVENT(p) do { if (n < max_events) { progress[n] = (p); rays[n] = base_rays + counters.rays; } n++; } while (0)
+    int pixel_count = pass->width * pass->height;
+    int ray_count = pixel_count * cam.rays_per_pixel;
+    ORC_EVENT(0.0f);
+    int update_interval = (int)((float)ray_count / 10.0f);
+    int update_index = 0;
+    int ri = 0;
+    for (int i = 0; i < pixel_count; ++i) {
+        int32_t x = i % pass->width, y = i / pass->width;
+        for (int j = 0; j < cam.rays_per_pixel; ++j) {
+            if (ri > update_index + update_interval) {
+                update_index = ri;
+                ORC_EVENT((float)update_index / (float)ray_count);
+            }
+            ri += 1;
+            uint64_t path = (uint64_t)i * (uint64_t)cam.rays_per_pixel + (uint64_t)j;
+            float o[3], d[3], rgb[3];
+            camera_ray(s, &cam, tl, steps, pass->x_offset, pass->y_offset, x, y, path, o, d);
+            trace(s, pass, &light, o, d, path, rgb, &counters);
+        }
+    }
+    ORC_EVENT(1.0f);
+#undef ORC_EVENT
+    return n;
+}
+

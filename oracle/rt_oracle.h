@@ -184,6 +184,11 @@ void orc_render_tile(orc_scene *s, const orc_pass *pass, int32_t sample_begin,
 void orc_resolve(const float *accum, int64_t pixels, int32_t divisor, int32_t gamma_on,
                  float gamma, uint8_t *rgba);
 
+/* main.go:117-154: the "trace" progress events of one render() call, each with
+ * the value of context.Rays at that moment; returns how many there are. */
+int32_t orc_render_progress(orc_scene *s, const orc_pass *pass, uint64_t base_rays,
+                            float *progress, uint64_t *rays, int32_t max_events);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,11 +404,36 @@ rt_status rtb_render(rtb_context *ctx, const char *pass_json, char **result_json
         return error_result(st, result_json_out, len);
     }
     ctx->last_image.assign((size_t)pass.width * (size_t)pass.height * 4, 0);
+    // main.go:117-122: an update whenever the running sample index passes
+    // updateIndex + updateInterval.  The tile is traced as a whole here, so the
+    // events go out together once it is done, with the values the reference's
+    // counter has at those sample indices.
+    rt::ProgressBins bins;
+    const int64_t ray_count = (int64_t)pass.width * (int64_t)pass.height * (int64_t)pass.camera.rays_per_pixel;
+    const int64_t interval = (int64_t)((float)ray_count / 10.0f);
+    const bool want_progress = ctx->progress != nullptr && pass.camera.rays_per_pixel > 0 && ray_count < (1LL << 31);
+    if (want_progress) {
+        bins.step = (uint32_t)(interval + 1);
+        int64_t events = (ray_count - 1) / (interval + 1);           // sample indices k * step <= ray_count - 1
+        if (events > rt::kProgressBins - 1) events = rt::kProgressBins - 1;
+        bins.n_bins = (int32_t)events + 1;
+    }
     rt_stats stats;
-    st = rt::render_tile_host(*ctx->scene, pass, ctx->mode, nullptr, ctx->last_image.data(), &stats);
+    st = rt::render_tile_host(*ctx->scene, pass, ctx->mode, nullptr, ctx->last_image.data(), &stats,
+                              want_progress ? &bins : nullptr);
     if (st != RT_OK) return error_result(st, result_json_out, len);
     ctx->last_w = pass.width;
     ctx->last_h = pass.height;
+    if (want_progress) {
+        const uint64_t before = ctx->rays;
+        uint64_t running = 0;
+        for (int32_t k = 1; k < bins.n_bins; ++k) {
+            running += bins.rays[k - 1];
+            ctx->rays = before + running;
+            send_progress(ctx, (float)((int64_t)k * (interval + 1)) / (float)ray_count, "trace", pass.task_id);
+        }
+        ctx->rays = before;
+    }
     ctx->rays += stats.rays;
     send_progress(ctx, 1.0f, "trace", pass.task_id);
     send_progress(ctx, 0.0f, "output", pass.task_id);

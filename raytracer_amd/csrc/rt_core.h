@@ -221,7 +221,8 @@ RT_HD void traverse_ref_order(const DevScene &s, const Ray<Real> &r, Hit<Real> &
 
 // The fast mode's ordered traversal, lane-serial form: nearer child first, the
 // farther one stacked with its entry distance and dropped at pop time once a
-// closer hit exists.  Box slabs use the reference's (bound - origin) * invDir;
+// closer hit exists (an entry AT the hit distance is kept: it may hold a
+// triangle that ties with the hit and sits earlier in the array).  Box slabs use the reference's (bound - origin) * invDir;
 // the triangle test is tri_test() unchanged, so t, u, v of a given triangle are
 // bit-identical to the reference order's.
 // Sorts four (entry distance, child ref) pairs by distance, ascending, with a
@@ -278,7 +279,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 const float tn = fmaxf(fmaxf(tna[0], tna[1]), tna[2]);
                 const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);
                 ref[k] = (uint32_t)f2i(q[12 + k]);
-                const bool hit = tn <= tf && tn < h.t && tf > 0 && ref[k] != kLeafBit;
+                const bool hit = tn <= tf && tn <= h.t && tf > 0 && ref[k] != kLeafBit;
                 key[k] = hit ? tn : kF32Inf;
                 n_hit += hit ? 1 : 0;
             }
@@ -287,7 +288,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 cur = kRefDone;
                 while (sp > 0) {
                     sp--;
-                    if (stack_t[sp] < h.t) { cur = stack_ref[sp]; break; }
+                    if (stack_t[sp] <= h.t) { cur = stack_ref[sp]; break; }
                 }
             } else {
                 // farthest first, so that the nearest of the rest is popped first
@@ -311,7 +312,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
         cur = kRefDone;
         while (sp > 0) {
             sp--;
-            if (stack_t[sp] < h.t) { cur = stack_ref[sp]; break; }
+            if (stack_t[sp] <= h.t) { cur = stack_ref[sp]; break; }
         }
         if (cur == kRefDone) return;
     }

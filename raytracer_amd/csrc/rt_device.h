@@ -54,6 +54,23 @@ struct PathBuffers {
     unsigned long long *ray_total;
     unsigned long long *trav_counters;   // 8 x u64, filled when the scene counts traversal work
     uint32_t *cursor;          // ray hand-out cursor of the traversal launches (fixed-block calls only)
+    // rays cast so far by each path of the batch; only kept (non-null) for calls that
+    // report the reference's progress events
+    uint32_t *path_rays;
+    unsigned long long *progress_bins;   // kProgressBins x u64
+};
+
+// The reference reports progress while it traces (main.go:120-154): an event
+// whenever the running camera-sample index passes updateIndex + updateInterval,
+// each with the ray counter's value at that moment.  A call that wants those
+// values gets, per bin j, the rays cast by the camera samples whose index (in
+// the reference's pixel-major order) lies in [j * step, (j + 1) * step), the
+// last bin taking all the rest.
+constexpr int kProgressBins = 16;
+struct ProgressBins {
+    uint32_t step = 1;                     // updateInterval + 1
+    int32_t n_bins = 1;                    // bins in use (at most kProgressBins)
+    unsigned long long rays[kProgressBins] = {};
 };
 
 struct Scene {
@@ -129,7 +146,7 @@ rt_status render_tile_static(Scene &sc, const rt_pass &pass, int mode, float *d_
 // Bytes of path workspace one camera sample in flight takes at these settings.
 size_t workspace_bytes_per_path(int light_samples, int bounce_limit);
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
-                           uint8_t *rgba, rt_stats *stats);
+                           uint8_t *rgba, rt_stats *stats, ProgressBins *progress = nullptr);
 rt_status gather_probe(int device, size_t table_bytes, double *records_per_s);
 rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, int gamma_on,
                          float gamma, uint8_t *d_rgba, hipStream_t stream);

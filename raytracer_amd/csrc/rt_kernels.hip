@@ -302,8 +302,12 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // of the tree behind the first hit is never fetched.  The stack's top kStackLds
 // entries live in LDS ([entry][lane], 8 bytes each: child reference + entry
 // distance), deeper entries spill to scratch.  A popped entry whose entry
-// distance is no longer below the current hit distance is dropped without
-// touching memory.  Triangle arithmetic is the reference's.
+// distance lies beyond the current hit distance is dropped without touching
+// memory; one AT the hit distance is kept, like a child box entered exactly at
+// it, because a triangle in it may tie with the current hit and sit earlier in
+// the array, and exact ties go to the earlier position (the triangle the
+// reference's left-first order meets first).  Triangle arithmetic is the
+// reference's.
 //
 // The loop alternates two phases, "descend through interior records until this
 // lane holds a leaf" and "test the leaf's triangles", so that the lanes of a
@@ -362,7 +366,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
             asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
             if (sp >= kStackLds) e = spill[sp - kStackLds];
-            if (i2f((int32_t)e.y) < h_t) {
+            if (i2f((int32_t)e.y) <= h_t) {
                 stand_on(e.x);
                 return true;
             }
@@ -452,7 +456,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                const bool hit = tn <= tf && tn < h_t && tf > 0 && ref[k] != kLeafBit;      \
+                const bool hit = tn <= tf && tn <= h_t && tf > 0 && ref[k] != kLeafBit;      \
                 key[k] = hit ? tn : kF32Inf;                                                \
             }
             RT_SLAB(0)
@@ -573,6 +577,7 @@ k_raygen(DevScene s, PassParams p, Batch b, PathBuffers w) {
     const uint64_t stream = rng_stream(ctx.rng_seed, ctx.path_index);
     // the primary ray of path `id` sits in slot `id` of queue 0
     w.head[id] = PathHead{(uint32_t)stream, (uint32_t)(stream >> 32), pack_head(kActive, 0, 0), id};
+    if (w.path_rays) w.path_rays[id] = 1;   // the primary ray
 }
 
 // Sum of the shadow samples that reached the light, scaled and clamped
@@ -646,6 +651,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     const uint64_t lbase = light_base(stream);
 
     // shadow rays of this vertex (the loop is uniform over the wave: L is a pass constant)
+    uint32_t cast_here = 0;
     for (int i = 0; i < p.L; ++i) {
         v3 dn{0, 0, 0}, col{0, 0, 0};
         float dist = 0;
@@ -654,6 +660,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
             cast = shadow_candidate(s, p, point, normal, diffuse,
                                     lbase + (uint64_t)k * (uint64_t)p.L + (uint64_t)i, dn, dist, col);
         const uint32_t q = block_append(out_count, cast, i);
+        cast_here += cast ? 1u : 0u;
         if (at_vertex) {
             if (cast) {
                 f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + q);
@@ -677,6 +684,7 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
         }
     }
     const uint32_t bq = block_append(out_count, bounce, p.L);
+    if (w.path_rays && at_vertex) w.path_rays[id] += cast_here + (bounce ? 1u : 0u);
     if (bounce) {
         f4 *rp = reinterpret_cast<f4 *>(w.rays[out] + bq);
         rp[0] = f4{point.x, point.y, point.z, kF32Max};
@@ -763,6 +771,27 @@ k_resolve(const float *__restrict__ accum, size_t pixels, float inv_divisor, int
     o.z = resolve_channel(accum[3 * i + 2], inv_divisor, gamma_on != 0, inv_gamma);
     o.w = 255;
     reinterpret_cast<uchar4 *>(rgba)[i] = o;
+}
+
+// Rays of the batch's paths, summed per progress bin (see ProgressBins): one
+// LDS atomic per path, one global atomic per bin and block.
+__global__ void __launch_bounds__(256)
+k_progress_bins(PassParams p, Batch b, const uint32_t *__restrict__ path_rays, uint32_t step, int n_bins,
+                unsigned long long *bins) {
+    __shared__ unsigned int part[kProgressBins];
+    if (threadIdx.x < kProgressBins) part[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < b.P) {
+        const uint32_t pl = id % b.n_pix, sl = id / b.n_pix;
+        const PathCtx ctx = locate_path(p, b.pix0 + pl, b.s0 + sl);
+        uint64_t bin = ctx.path_index / step;
+        if (bin > (uint64_t)(n_bins - 1)) bin = (uint64_t)(n_bins - 1);
+        atomicAdd(&part[bin], path_rays[id]);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)n_bins && part[threadIdx.x])
+        atomicAdd(bins + threadIdx.x, (unsigned long long)part[threadIdx.x]);
 }
 
 __global__ void k_sum_counts(const uint32_t *counts, int n, unsigned long long *total) {
@@ -1199,7 +1228,7 @@ rt_status trace_rays_host(Scene &sc, const rt_ray *rays, size_t n, rt_hit *hits,
 // scene) or from the library's static device array alike.
 // ---------------------------------------------------------------------------
 struct WsLayout {
-    size_t rays[2], hits[2], counts, head, slots, terms_a, terms_b, radiance, ray_total, trav, cursor;
+    size_t rays[2], hits[2], counts, head, slots, terms_a, terms_b, radiance, ray_total, trav, cursor, path_rays, bins;
     size_t total;
 };
 
@@ -1225,6 +1254,8 @@ static WsLayout ws_layout(size_t P, int L, int B) {
     l.ray_total = take(64);
     l.trav = take(8 * sizeof(unsigned long long));
     l.cursor = take((size_t)kCursorStride * sizeof(uint32_t));
+    l.path_rays = take(P * sizeof(uint32_t));
+    l.bins = take((size_t)kProgressBins * sizeof(unsigned long long));
     l.total = at;
     return l;
 }
@@ -1245,13 +1276,15 @@ static PathBuffers ws_carve(void *block, const WsLayout &l) {
     b.ray_total = reinterpret_cast<unsigned long long *>(base + l.ray_total);
     b.trav_counters = reinterpret_cast<unsigned long long *>(base + l.trav);
     b.cursor = reinterpret_cast<uint32_t *>(base + l.cursor);
+    b.path_rays = reinterpret_cast<uint32_t *>(base + l.path_rays);
+    b.progress_bins = reinterpret_cast<unsigned long long *>(base + l.bins);
     return b;
 }
 
 size_t workspace_bytes_per_path(int L, int B) {
     const size_t Lc = (size_t)(L > 0 ? L : 1), nv = (size_t)(B > 0 ? B : 0) + 1;
     return 2 * (Lc + 1) * (sizeof(rt_ray) + sizeof(rt_hit)) + sizeof(PathHead) + Lc * sizeof(f4) +
-           nv * (sizeof(f4) + sizeof(Pair32)) + 3 * sizeof(float);
+           nv * (sizeof(f4) + sizeof(Pair32)) + 3 * sizeof(float) + sizeof(uint32_t);
 }
 
 // Grow-only workspace for `paths` simultaneous paths with L light samples and
@@ -1311,10 +1344,13 @@ static bool same_frame(const rt_pass &a, const rt_pass &b) {
 static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes, int mode,
                              int32_t sample_begin, int32_t sample_count, bool incremental,
                              bool zero_accum, float *d_accum, uint8_t *d_rgba, rt_stats *stats,
-                             hipStream_t stream, FixedWorkspace *fixed, size_t fixed_paths) {
+                             hipStream_t stream, FixedWorkspace *fixed, size_t fixed_paths,
+                             ProgressBins *progress = nullptr) {
     DeviceGuard guard(sc.device);
     if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     if (fixed && (stats || n_passes != 1)) return fail(RT_ERR_INVALID, "the static-workspace call takes one pass and no statistics");
+    if (progress && (fixed || n_passes != 1 || incremental || progress->n_bins < 1 || progress->n_bins > kProgressBins || progress->step < 1))
+        return fail(RT_ERR_INVALID, "progress bins need one whole-tile pass on the scene's own workspace");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (!passes || n_passes < 1) return fail(RT_ERR_INVALID, "no pass given");
     if (n_passes > 65536) return fail(RT_ERR_INVALID, "more than 65536 tiles in one call");
@@ -1403,6 +1439,8 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
     }
 
     const DevScene d = dev_view(sc);
+    if (progress) HIP_TRY(hipMemsetAsync(w.progress_bins, 0, kProgressBins * sizeof(unsigned long long), stream));
+    else w.path_rays = nullptr;            // the kernels keep no per-path ray counts
     if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
     if (stats) {
         HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
@@ -1455,6 +1493,9 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
             hipLaunchKernelGGL(k_finish, grid, block, 0, stream, d, pp, b, w, (B + 1) & 1);
             hipLaunchKernelGGL(k_accumulate, dim3((b.n_pix + 255) / 256), block, 0, stream, b, w.radiance, d_accum);
             if (stats) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, w.counts, B + 2, w.ray_total);
+            if (progress)
+                hipLaunchKernelGGL(k_progress_bins, grid, block, 0, stream, pp, b, w.path_rays, progress->step,
+                                   progress->n_bins, w.progress_bins);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1465,6 +1506,11 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
         hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream,
                            d_accum, pixels, inv, pass.settings.gamma_correction, inv_gamma, d_rgba);
         HIP_TRY(hipGetLastError());
+    }
+    if (progress) {
+        HIP_TRY(hipMemcpyAsync(progress->rays, w.progress_bins, kProgressBins * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
     }
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
@@ -1638,7 +1684,7 @@ rt_status resolve_device(const float *d_accum, size_t pixels, int32_t divisor, i
 }
 
 rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accum_rgb,
-                           uint8_t *rgba, rt_stats *stats) {
+                           uint8_t *rgba, rt_stats *stats, ProgressBins *progress) {
     DeviceGuard guard(sc.device);
     if (!rgba) return fail(RT_ERR_INVALID, "rgba is NULL");
     if (pass.width <= 0 || pass.height <= 0) return fail(RT_ERR_INVALID, "pass width/height must be positive");
@@ -1651,8 +1697,8 @@ rt_status render_tile_host(Scene &sc, const rt_pass &pass, int mode, float *accu
         return fail(RT_ERR_NOMEM, "hipMalloc of the tile image failed");
     }
     rt_stats local;
-    rt_status st = render_accumulate(sc, &pass, 1, mode, 0, pass.camera.rays_per_pixel, false, true,
-                                     d_accum, d_rgba, stats ? stats : &local, nullptr);
+    rt_status st = render_core(sc, &pass, 1, mode, 0, pass.camera.rays_per_pixel, false, true, d_accum,
+                               d_rgba, stats ? stats : &local, nullptr, nullptr, 0, progress);
     if (st == RT_OK) {
         hipError_t e = hipMemcpy(rgba, d_rgba, pixels * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && accum_rgb) e = hipMemcpy(accum_rgb, d_accum, pixels * 12, hipMemcpyDeviceToHost);

@@ -195,12 +195,52 @@ def test_cornell_preset_tile_by_tile_against_oracle(product_lib, oracle, gpu_dev
     assert b.rays == total_rays
     assert frame[..., :3].mean() > 40 and (frame[..., 3] == 255).all()
     trace_events = [json.loads(e) for e in events if json.loads(e)["event"] == "trace"]
-    assert len(trace_events) == 32 and trace_events[-1]["rays"] == total_rays
+    # per tile: 0.0, nine intermediate updates, 1.0 (main.go:120-154)
+    assert len(trace_events) == 16 * 11 and trace_events[-1]["rays"] == total_rays
+    assert all(a["rays"] <= b["rays"] for a, b in zip(trace_events, trace_events[1:]))
     # a new RenderKey resets the counter (main.go:107-110)
     d = _tasks(spp=1)[0]
     d["RenderKey"] = 2
     b.render(json.dumps(d))
     assert 0 < b.rays < total_rays
+
+
+@pytest.mark.gpu
+def test_render_progress_events_follow_the_reference(product_lib, oracle, gpu_device):
+    """One 62x62 tile of the preset at its own 25 spp, 6 light samples, 3
+    bounces: the progressUpdate documents are the ones main.go:120-156,185
+    issues -- trace 0.0, an update whenever the running sample index passes
+    updateIndex + updateInterval (progress = updateIndex / rayCount, rays = the
+    counter's value at that sample), trace 1.0, output 0.0, output 1.0 -- with
+    the oracle's running ray counts, continued from the counter of earlier
+    calls with the same RenderKey."""
+    events = []
+    b = backend.Backend(device=gpu_device, progressUpdate=events.append)
+    b.initialize(_context_json())
+    b.loadBVH(b.buildBVH())
+    sc = cornell()
+    bvh = api.Bvh.build(product_mesh(sc), True, 6, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    osc.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
+                          api.default_sample_table(100001, 0xC0FFEE02))
+    tasks = _tasks(spp=25)
+    base = 0
+    for d in (tasks[5], tasks[15]):            # a 62x62 tile, then the 64x64 corner tile
+        del events[:]
+        doc = json.loads(b.render(json.dumps(d)))
+        assert doc["exitCode"] == 0
+        want = oracle.render_progress(osc, oracle.pass_from_dict(d), base_rays=base)
+        assert len(want) == 11
+        got = [json.loads(e) for e in events]
+        assert [e["event"] for e in got] == ["trace"] * 11 + ["output"] * 2
+        assert all(e["taskId"] == d["TaskID"] for e in got)
+        for e, (progress, rays) in zip(got[:11], want):
+            assert np.float32(e["progress"]) == np.float32(progress), (e, progress)
+            assert e["rays"] == rays, (e, rays)
+        assert [e["progress"] for e in got[11:]] == [0, 1]
+        assert got[11]["rays"] == got[12]["rays"] == want[-1][1] == b.rays
+        base = b.rays
+    assert d["Width"] == 64 and tasks[5]["Width"] == 62
 
 
 @pytest.mark.gpu
