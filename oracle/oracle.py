@@ -94,6 +94,7 @@ def lib():
                                       vp, vp, vp, C.POINTER(Counters)]
         L.orc_render_progress.restype = C.c_int32
         L.orc_render_progress.argtypes = [vp, C.POINTER(Pass), C.c_uint64, vp, vp, C.c_int32]
+        L.orc_set_light_index_mode.argtypes = [vp, C.c_int32]
         L.orc_resolve.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]
         L.orc_aabb_intersect.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -244,6 +245,10 @@ class Scene:
         c = np.ascontiguousarray(camera_tab, np.float64).reshape(-1, 2)
         l = np.ascontiguousarray(light_tab, np.float64).reshape(-1, 2)
         lib().orc_set_sample_tables(self._h, _ptr(c), c.shape[0], _ptr(l), l.shape[0])
+
+    def set_light_index_mode(self, mode):
+        """0: hashed row per camera sample; 1: the reference's advancing index per light."""
+        lib().orc_set_light_index_mode(self._h, int(mode))
 
     def trace_rays(self, rays, tmax=None, mode=MODE_F32, counters=False):
         """rays: (n,6) origin+direction.  Returns dict(tri, t, u, v[, counters])."""

@@ -61,6 +61,14 @@ struct orc_scene {
     int32_t n_cam;
     double *light_tab;
     int32_t n_light;
+    /* 0: the build's row index, a hash of the camera sample's stream + the
+     * sample's running number along the path (what the GPU kernels use);
+     * 1: the reference's own scheme, ONE index per light that advances with
+     * every Sample() call for the lifetime of the worker and wraps at the
+     * table's end (arealight.go:42-56).  Mode 1 is serial by nature; it exists
+     * to compare image statistics of the two schemes. */
+    int32_t light_index_mode;
+    uint64_t *light_cursor;
 };
 
 #define COUNT(c, f) do { if (c) (c)->f++; } while (0)
@@ -468,6 +476,7 @@ void orc_scene_destroy(orc_scene *s)
     free(s->tex);
     free(s->store); free(s->tris); free(s->kd); free(s->mat_light);
     free(s->cam_tab); free(s->light_tab);
+    free(s->light_cursor);
     free(s);
 }
 
@@ -492,6 +501,13 @@ int32_t orc_scene_set_texture(orc_scene *s, int32_t material, const uint8_t *rgb
     t->w = w;
     t->h = h;
     return 0;
+}
+
+void orc_set_light_index_mode(orc_scene *s, int32_t mode)
+{
+    if (!s->light_cursor) s->light_cursor = (uint64_t *)calloc(1, sizeof(uint64_t));
+    *s->light_cursor = 0;
+    s->light_index_mode = mode;
 }
 
 void orc_set_sample_tables(orc_scene *s, const double *camera_tab, int32_t n_camera,
@@ -1069,7 +1085,9 @@ static void trace(const orc_scene *s, const orc_pass *pass, const orc_light *lig
 
         for (int i = 0; i < L; ++i) {
             float ls[3], pdf;
-            light_sample(s, light, light_base + light_count++, ls, &pdf);
+            uint64_t row = light_base + light_count++;
+            if (s->light_index_mode == 1) row = (*s->light_cursor)++;
+            light_sample(s, light, row, ls, &pdf);
             float sr[3] = {ls[0] - res.point[0], ls[1] - res.point[1], ls[2] - res.point[2]};
             float dist = len3(sr);
             float srn[3];

@@ -184,6 +184,11 @@ void orc_render_tile(orc_scene *s, const orc_pass *pass, int32_t sample_begin,
 void orc_resolve(const float *accum, int64_t pixels, int32_t divisor, int32_t gamma_on,
                  float gamma, uint8_t *rgba);
 
+/* Light-table row per Sample() call: 0 = hashed per camera sample (default,
+ * what the kernels use), 1 = the reference's single advancing index per light
+ * (arealight.go:42-56; serial, for comparing image statistics). */
+void orc_set_light_index_mode(orc_scene *s, int32_t mode);
+
 /* main.go:117-154: the "trace" progress events of one render() call, each with
  * the value of context.Rays at that moment; returns how many there are. */
 int32_t orc_render_progress(orc_scene *s, const orc_pass *pass, uint64_t base_rays,

@@ -107,3 +107,33 @@ def test_rng_is_uniform_24bit(oracle):
     assert abs(xs.mean() - 0.5) < 0.01
     assert np.all(xs * 2 ** 24 == np.floor(xs * 2 ** 24))
     assert L.orc_rng_stream(5, 18) != s and L.orc_rng_stream(6, 17) != s
+
+
+def test_hashed_light_rows_give_the_image_statistics_of_the_advancing_index(oracle):
+    """The reference draws light samples with ONE index per light that advances
+    with every Sample() call (arealight.go:42-56); a GPU cannot keep that serial
+    counter, so the kernels (and the oracle's default) take the table row from a
+    hash of the camera sample's stream.  Both walk the same table; on the Cornell
+    preset the two schemes must agree in everything but noise: frame mean within
+    1 %, means of 8x8-pixel blocks within a few standard errors."""
+    from raytracer_amd import api, scenes
+    from util import cornell, oracle_scene
+    sc = cornell()
+    osc = oracle_scene(oracle, sc, build=(True, 6, 16))
+    osc.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
+                          api.default_sample_table(100001, 0xC0FFEE02))
+    d = scenes.make_pass_dict(250, 250, {"x": -0.225, "y": 2.55, "z": 6.0}, spp=48, bounces=3,
+                              light_samples=6, intensity=100.0, seed=1, x_offset=93, y_offset=93,
+                              tile_w=64, tile_h=64, task_id=5, gamma_on=False)
+    p = oracle.pass_from_dict(d)
+    hashed = osc.render_tile(p)["accum"] / 48.0
+    osc.set_light_index_mode(1)
+    stateful = osc.render_tile(p)["accum"] / 48.0
+    osc.set_light_index_mode(0)
+    assert not np.array_equal(hashed, stateful)
+    assert abs(hashed.mean() - stateful.mean()) < 0.01 * stateful.mean()
+    blocks = lambda a: a.reshape(8, 8, 8, 8, 3).mean(axis=(1, 3))
+    bh, bs = blocks(hashed), blocks(stateful)
+    # per-pixel sample noise of this scene is below 0.35 at 1 spp; a block has 64 pixels x 48 samples
+    tol = 4 * 0.35 / np.sqrt(64 * 48) + 0.02 * bs
+    assert (np.abs(bh - bs) < tol).all(), float(np.abs(bh - bs).max())
