@@ -109,9 +109,6 @@ struct Scene {
     int tune_blocks_per_cu = 8;   // persistent grid size
     int tune_leaf_min = 0;        // leave the leaf phase below this many lanes in a leaf (0 = per-kernel default)
     int tune_descend_min = 0;     // leave the descent phase below this many descending lanes (0 = per-kernel default)
-    int tune_pool = 0;             // experiment: ordered mode runs k_trace_pool (value picks slots / stack entries)
-    int tune_pool_refill = 24, tune_pool_leaf_start = 48, tune_pool_desc_low = 16;
-    uint2 *d_pool_spill = nullptr;
     bool count_traversal = false;   // render calls run the counting kernel variant
     size_t ws_paths = 0;
     int ws_L = 0, ws_B = 0;

@@ -543,264 +543,6 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 }
 
 // ---------------------------------------------------------------------------
-// Ordered traversal over a POOL of rays per wave.  The step code is
-// k_trace_fast's; what changes is where a ray lives.  In k_trace_fast a lane
-// owns one ray in registers, so a lane whose ray waits in a leaf idles through
-// the descent steps and the other way round: the kernel issues VALU
-// instructions on every cycle with half the lanes idle.  Here a wave owns S > 64
-// ray slots in LDS (structure of arrays: where, stack height, origin, inverse
-// direction, hit distance and position, u, v, ray index, direction; K stack
-// entries per slot, deeper entries in a per-slot strip of global memory).  A
-// lane is a worker: every iteration the wave votes on the slots' states, picks
-// the phase that has more work (descent, or leaves once enough have piled up),
-// hands the first 64 slots in that phase to its lanes (ballot + prefix count
-// through a small LDS list), and each lane loads its slot's state, runs one
-// step and stores what changed.  Results and counters equal k_trace_fast's:
-// the per-ray sequence of steps is the same.
-// ---------------------------------------------------------------------------
-constexpr uint32_t kRefFree = 0xFFFFFFFEu;   // slot without a ray (a leaf reference that is never built, see kFastMaxTris)
-constexpr int kPoolSpill = kFastStackEntries;   // entries of a slot's global strip (indexed by stack height)
-
-enum : int { PF_WHERE = 0, PF_SP, PF_OX, PF_OY, PF_OZ, PF_IX, PF_IY, PF_IZ, PF_HT, PF_HPOS,
-             PF_U, PF_V, PF_IDX, PF_DX, PF_DY, PF_DZ, PF_COUNT };
-
-template <bool COUNT, int S, int K>
-__global__ void __launch_bounds__(256)
-k_trace_pool(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
-             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters, uint2 *__restrict__ spill_all,
-             int refill_at, int leaf_start, int desc_low) {
-    static_assert(S > 64 && S <= 128, "a lane looks at slots lane and lane + 64");
-    constexpr int kWaveWords = PF_COUNT * S + 2 * K * S + 64;
-    __shared__ __align__(16) uint32_t lds[4 * kWaveWords];
-    const uint32_t n = n_dev ? *n_dev : n_host;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t *const st = lds + wave * kWaveWords;              // st[field * S + slot]
-    uint2 *const stk = reinterpret_cast<uint2 *>(st + PF_COUNT * S);   // stk[entry * S + slot]
-    uint32_t *const list = st + PF_COUNT * S + 2 * K * S;      // slots chosen for this step
-    uint2 *const spill = spill_all + ((size_t)blockIdx.x * 4 + wave) * (size_t)S * kPoolSpill;
-    RayFeed feed;
-    uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
-
-    // every slot starts free
-    st[PF_WHERE * S + lane] = kRefFree;
-    if (lane + 64 < (uint32_t)S) st[PF_WHERE * S + lane + 64] = kRefFree;
-    __builtin_amdgcn_wave_barrier();
-
-    const uint32_t s1 = lane + 64;                 // this lane's second slot
-    const bool has1 = s1 < (uint32_t)S;
-
-    uint32_t iters = 0;
-    for (;;) {
-        if (++iters > 4000000u) {                  // debugging guard: leave a trace and get out
-            if (COUNT && lane == 0) {
-                atomicAdd(counters + 5, 1ull << 40);
-                atomicMax(counters + 6, ((unsigned long long)feed.pos << 32) | feed.end);
-                atomicMax(counters + 7, (unsigned long long)st[PF_WHERE * S + 0]);
-            }
-            break;
-        }
-        // the wave's vote on its slots
-        const uint32_t w0 = st[PF_WHERE * S + lane];
-        const uint32_t w1 = has1 ? st[PF_WHERE * S + s1] : kRefFree;
-        const bool d0 = (w0 & kLeafBit) == 0, d1 = has1 && (w1 & kLeafBit) == 0;
-        const bool l0 = (w0 & kLeafBit) != 0 && w0 < kRefFree, l1 = has1 && (w1 & kLeafBit) != 0 && w1 < kRefFree;
-        const bool x0 = w0 == kRefDone, x1 = has1 && w1 == kRefDone;
-        const bool f0 = w0 == kRefFree, f1 = has1 && w1 == kRefFree;
-        const uint64_t md0 = __ballot(d0), md1 = __ballot(d1), ml0 = __ballot(l0), ml1 = __ballot(l1);
-        const int n_desc = (int)__popcll(md0) + (int)__popcll(md1);
-        const int n_leaf = (int)__popcll(ml0) + (int)__popcll(ml1);
-        const int n_done = (int)__popcll(__ballot(x0)) + (int)__popcll(__ballot(x1));
-        const int n_free = (int)__popcll(__ballot(f0)) + (int)__popcll(__ballot(f1));
-        const bool feed_empty = feed.exhausted && feed.pos >= feed.end;
-
-        // retire finished rays and take new ones: each lane serves one of its two slots per pass
-        if ((n_desc + n_leaf == 0) || n_done >= refill_at || (!feed_empty && n_done + n_free >= refill_at)) {
-            if (n_desc + n_leaf + n_done == 0 && feed_empty) break;
-            // a finished ray goes first: a free slot can wait (and waits for ever once the feed is dry)
-            const bool serve0 = x0 || (f0 && !x1), serve1 = !serve0 && (x1 || f1);
-            const uint32_t slot = serve0 ? lane : s1;
-            const bool was_done = serve0 ? x0 : x1;
-            if ((serve0 || serve1) && was_done) {
-                f4 out;
-                out.x = i2f((int32_t)st[PF_HPOS * S + slot]);
-                out.y = i2f((int32_t)st[PF_HT * S + slot]);
-                out.z = i2f((int32_t)st[PF_U * S + slot]);
-                out.w = i2f((int32_t)st[PF_V * S + slot]);
-                const int32_t idx = (int32_t)st[PF_IDX * S + slot];
-                *reinterpret_cast<f4 *>(hits + idx) = out;
-                st[PF_WHERE * S + slot] = kRefFree;
-            }
-            if (!feed_empty) {
-                const int32_t mine = feed_take(feed, next, n, __ballot(serve0 || serve1));
-                if (mine >= 0) {
-                    const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
-                    const f4 a = rp[0], b = rp[1];
-                    st[PF_OX * S + slot] = (uint32_t)f2i(a.x);
-                    st[PF_OY * S + slot] = (uint32_t)f2i(a.y);
-                    st[PF_OZ * S + slot] = (uint32_t)f2i(a.z);
-                    st[PF_IX * S + slot] = (uint32_t)f2i(1.0f / b.x);      // ray.go:33-37
-                    st[PF_IY * S + slot] = (uint32_t)f2i(1.0f / b.y);
-                    st[PF_IZ * S + slot] = (uint32_t)f2i(1.0f / b.z);
-                    st[PF_HT * S + slot] = (uint32_t)f2i(a.w);
-                    st[PF_HPOS * S + slot] = 0xFFFFFFFFu;                  // -1
-                    st[PF_U * S + slot] = 0;
-                    st[PF_V * S + slot] = 0;
-                    st[PF_IDX * S + slot] = (uint32_t)mine;
-                    st[PF_DX * S + slot] = (uint32_t)f2i(b.x);
-                    st[PF_DY * S + slot] = (uint32_t)f2i(b.y);
-                    st[PF_DZ * S + slot] = (uint32_t)f2i(b.z);
-                    st[PF_SP * S + slot] = 0;
-                    st[PF_WHERE * S + slot] = s.fast_root;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-
-        // phase of this step: leaves once enough of them wait (or little is left to descend)
-        const bool leaf_phase = n_leaf > 0 && (n_leaf >= leaf_start || n_desc < desc_low);
-        const uint64_t m0 = leaf_phase ? ml0 : md0, m1 = leaf_phase ? ml1 : md1;
-        const uint32_t r0 = (uint32_t)__popcll(m0 & lanemask_lt());
-        const uint32_t r1 = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lanemask_lt());
-        if (((m0 >> lane) & 1ull) && r0 < 64) list[r0] = lane;
-        if (((m1 >> lane) & 1ull) && r1 < 64) list[r1] = s1;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n_sel = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
-        const bool active = lane < (n_sel < 64u ? n_sel : 64u);
-        const uint32_t slot = active ? list[lane] : 0u;
-        __builtin_amdgcn_wave_barrier();
-
-        if (active) {
-            uint32_t where = st[PF_WHERE * S + slot];
-            int32_t sp = (int32_t)st[PF_SP * S + slot];
-            const float r_ox = i2f((int32_t)st[PF_OX * S + slot]), r_oy = i2f((int32_t)st[PF_OY * S + slot]),
-                        r_oz = i2f((int32_t)st[PF_OZ * S + slot]);
-            const float r_ix = i2f((int32_t)st[PF_IX * S + slot]), r_iy = i2f((int32_t)st[PF_IY * S + slot]),
-                        r_iz = i2f((int32_t)st[PF_IZ * S + slot]);
-            float h_t = i2f((int32_t)st[PF_HT * S + slot]);
-            uint2 *const my_spill = spill + (size_t)slot * kPoolSpill;
-            auto push = [&](uint32_t ref, float tn) {
-                const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
-                if (sp < K) stk[sp * S + slot] = e;
-                else if (sp < kStackTotal) my_spill[sp] = e;
-                sp++;
-            };
-            auto pop_next = [&]() {
-                while (sp > 0) {
-                    sp--;
-                    const uint2 e = sp < K ? stk[sp * S + slot] : my_spill[sp];
-                    if (i2f((int32_t)e.y) <= h_t) {
-                        where = e.x;
-                        return;
-                    }
-                }
-                where = kRefDone;
-            };
-            if (!leaf_phase) {
-                const f4 *q = s.wide + 4 * (size_t)where;
-                const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
-                const f2 fo_x{q0.x, q0.x}, fo_y{q0.y, q0.y}, fo_z{q0.z, q0.z};
-                const f2 fs_x{q0.w, q0.w}, fs_y{q1.x, q1.x}, fs_z{q1.y, q1.y};
-                const bool nx = r_ix < 0, ny = r_iy < 0, nz = r_iz < 0;
-                const uint32_t lox = (uint32_t)f2i(q1.z), loy = (uint32_t)f2i(q1.w), loz = (uint32_t)f2i(q2.x);
-                const uint32_t hix = (uint32_t)f2i(q2.y), hiy = (uint32_t)f2i(q2.z), hiz = (uint32_t)f2i(q2.w);
-                const uint32_t plx = nx ? hix : lox, ply = ny ? hiy : loy, plz = nz ? hiz : loz;   // near
-                const uint32_t phx = nx ? lox : hix, phy = ny ? loy : hiy, phz = nz ? loz : hiz;   // far
-                const f2 ox{r_ox, r_ox}, oy{r_oy, r_oy}, oz{r_oz, r_oz};
-                const f2 ix{r_ix, r_ix}, iy{r_iy, r_iy}, iz{r_iz, r_iz};
-                float key[4];
-                uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
-#define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
-#define RT_SLAB(k)                                                                          \
-                {                                                                           \
-                    const f2 bx = __builtin_elementwise_fma(f2{RT_BYTE(plx, k), RT_BYTE(phx, k)}, fs_x, fo_x); \
-                    const f2 by = __builtin_elementwise_fma(f2{RT_BYTE(ply, k), RT_BYTE(phy, k)}, fs_y, fo_y); \
-                    const f2 bz = __builtin_elementwise_fma(f2{RT_BYTE(plz, k), RT_BYTE(phz, k)}, fs_z, fo_z); \
-                    const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz; \
-                    const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                        \
-                    const float tf = fminf(fminf(tx.y, ty.y), tz.y);                        \
-                    const bool hit = tn <= tf && tn <= h_t && tf > 0 && ref[k] != kLeafBit; \
-                    key[k] = hit ? tn : kF32Inf;                                            \
-                }
-                RT_SLAB(0)
-                RT_SLAB(1)
-                RT_SLAB(2)
-                RT_SLAB(3)
-#undef RT_SLAB
-#undef RT_BYTE
-                wide_sort4(key, ref);
-                if (!(key[0] < kF32Inf)) {
-                    pop_next();
-                } else {
-                    if (key[3] < kF32Inf) push(ref[3], key[3]);
-                    if (key[2] < kF32Inf) push(ref[2], key[2]);
-                    if (key[1] < kF32Inf) push(ref[1], key[1]);
-                    where = ref[0];
-                }
-            } else {
-                const int32_t tri_i = (int32_t)(where & 0xFFFFFFu), tri_n = (int32_t)((where >> 24) & 0x7Fu);
-                const bool two = tri_n > 1;
-                const f4 *qa = s.tris + 3 * (size_t)tri_i;
-                const f4 *qb = qa + (two ? 3 : 0);
-                const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
-                const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-                if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
-                Ray<float> r;
-                r.ox = r_ox; r.oy = r_oy; r.oz = r_oz;
-                r.dx = i2f((int32_t)st[PF_DX * S + slot]);
-                r.dy = i2f((int32_t)st[PF_DY * S + slot]);
-                r.dz = i2f((int32_t)st[PF_DZ * S + slot]);
-                r.ix = r_ix; r.iy = r_iy; r.iz = r_iz;
-                const int32_t h_pos = (int32_t)st[PF_HPOS * S + slot];
-                Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
-                bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
-                if (COUNT && tested) c_test++;
-                if (two) {
-                    tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
-                    if (COUNT && tested) c_test++;
-                }
-                if (h.pos != h_pos) {      // a triangle is accepted at most once
-                    st[PF_U * S + slot] = (uint32_t)f2i(h.u);
-                    st[PF_V * S + slot] = (uint32_t)f2i(h.v);
-                    st[PF_HPOS * S + slot] = (uint32_t)h.pos;
-                    st[PF_HT * S + slot] = (uint32_t)f2i(h.t);
-                }
-                h_t = h.t;
-                if (tri_n <= 2) {
-                    pop_next();
-                } else {
-                    where = kLeafBit | ((uint32_t)(tri_n - 2) << 24) | (uint32_t)(tri_i + 2);
-                }
-            }
-            st[PF_WHERE * S + slot] = where;
-            st[PF_SP * S + slot] = (uint32_t)sp;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (COUNT) {
-        c_nodes = wave_sum(c_nodes);
-        c_box = wave_sum(c_box);
-        c_fetch = wave_sum(c_fetch);
-        c_test = wave_sum(c_test);
-        c_wa = wave_sum(c_wa);
-        c_wb = wave_sum(c_wb);
-        c_lb = wave_sum(c_lb);
-        if (lane == 0) {
-            atomicAdd(counters + 5, (unsigned long long)c_wa);
-            atomicAdd(counters + 6, (unsigned long long)c_wb);
-            atomicAdd(counters + 7, (unsigned long long)c_lb);
-            atomicAdd(counters + 1, (unsigned long long)c_nodes);
-            atomicAdd(counters + 2, (unsigned long long)c_box);
-            atomicAdd(counters + 3, (unsigned long long)c_fetch);
-            atomicAdd(counters + 4, (unsigned long long)c_test);
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + 0, (unsigned long long)n);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Path-tracing wavefront kernels
 // ---------------------------------------------------------------------------
 enum : uint32_t { kDone = 0, kActive = 1, kLastVertex = 2, kComplete = 3 };
@@ -1196,11 +938,6 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount;
-    if (const char *e = std::getenv("RT_POOL")) {     // experiment knob: "variant,refill,leaf_start,desc_low"
-        int a = 0, b = 24, c = 48, dd = 16;
-        std::sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &dd);
-        sc->tune_pool = a; sc->tune_pool_refill = b; sc->tune_pool_leaf_start = c; sc->tune_pool_desc_low = dd;
-    }
 
     FlatScene flat;
     rt_status st = flatten(mesh, bvh, flat);
@@ -1313,7 +1050,7 @@ void scene_destroy(Scene *sc) {
     workspace_free(*sc);
     for (uint8_t *p : sc->tex_ptrs)
         if (p) (void)hipFree(p);
-    void *ptrs[] = {sc->d_pool_spill, sc->d_linked, sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_shade, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
+    void *ptrs[] = {sc->d_linked, sc->d_wide, sc->d_tiles, sc->d_nodes, sc->d_tris, sc->d_tri_shade, sc->d_kd, sc->d_tri_uv, sc->d_mat_tex,
                     sc->d_tex_ptrs, sc->d_tex_dims, sc->d_cam_tab, sc->d_light_tab, sc->d_cursors};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1387,30 +1124,6 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     case RT_MODE_FAST_F32:
         if (sc.d_wide) {
             const int rb = t_refill;
-            if (sc.tune_pool) {
-                // experiment: pooled kernel; its spill strips are allocated on first use
-                const int per_cu = sc.tune_blocks_per_cu < 4 ? sc.tune_blocks_per_cu : 4;
-                size_t blocks = (size_t)sc.num_cus * (size_t)per_cu;
-                const size_t chunks = (n_host + 255) / 256;
-                if (blocks > chunks) blocks = chunks;
-                if (blocks == 0) blocks = 1;
-                const size_t need = (size_t)sc.num_cus * 4 * 4 * 128 * kPoolSpill * sizeof(uint2);
-                if (!sc.d_pool_spill) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc.d_pool_spill), need));
-                const dim3 pgrid((uint32_t)blocks);
-                const int ra = sc.tune_pool_refill, ls = sc.tune_pool_leaf_start, dl = sc.tune_pool_desc_low;
-#define RT_POOL(C, SS, KK) hipLaunchKernelGGL((k_trace_pool<C, SS, KK>), pgrid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, sc.d_pool_spill, ra, ls, dl)
-                if (d_counters) RT_POOL(true, 96, 4);
-                else switch (sc.tune_pool) {
-                    case 1: RT_POOL(false, 96, 4); break;
-                    case 2: RT_POOL(false, 80, 4); break;
-                    case 3: RT_POOL(false, 96, 6); break;
-                    case 4: RT_POOL(false, 128, 4); break;
-                    case 5: RT_POOL(false, 112, 2); break;
-                    default: RT_POOL(false, 80, 6); break;
-                }
-#undef RT_POOL
-                break;
-            }
             if (d_counters) {
                 hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
             } else {
