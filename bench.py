@@ -229,7 +229,30 @@ def main():
     t0 = time.perf_counter()
     sc = scenes.room_mesh(wl["grid"], seed=wl.get("seed", 0x5EED0002), total=wl["tris"])
     mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
-    bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
+    if world == 1:
+        bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
+    else:
+        # the reference's flow: worker 0 builds the tree, every worker loads it
+        # (main.go:65-90, Renderer.js:235-297); here through the binary cache file
+        import tempfile
+        cache = os.path.join(tempfile.gettempdir(),
+                             f"rt_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.bvh")
+        bvh = None
+        if rank == 0:
+            bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
+            try:
+                bvh.save(cache)
+            except Exception:                      # noqa: BLE001 - the others then build for themselves
+                pass
+        dist.barrier()
+        if rank != 0:
+            try:
+                bvh = api.Bvh.load(mesh, cache)
+            except Exception:                      # noqa: BLE001
+                bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
+        dist.barrier()
+        if rank == 0 and os.path.exists(cache):
+            os.remove(cache)
     scene = api.Scene(mesh, bvh, local_rank)
     setup_s = time.perf_counter() - t0
     if args.tune:

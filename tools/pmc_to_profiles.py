@@ -21,7 +21,7 @@ Normalisation, written into the file as well:
       the chip has 1024 SIMDs, and a VALU instruction occupies its SIMD for 4 cycles
   hbm_bytes_per_ray = (FETCH_SIZE + WRITE_SIZE) * 1024 / rays         (counters are in KB; no x2:
       for scattered 64-byte records FETCH_SIZE reads the requested bytes as they are, calibrated
-      with the gather probe in round 1, profiles/traffic.json)
+      with the gather probe, see the calibration note in profiles/traffic.json)
 """
 import csv
 import glob

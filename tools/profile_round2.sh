@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence on one MI355X (run through gpurun): bench lines, kernel
+# Profiling evidence on one MI355X (run through gpurun): bench lines, kernel
 # stats, and the counter passes bench.py's roofline constants come from.
 #   bash tools/profile_round2.sh [cfg3|cfg4]
 # Every GPU step has its own time limit; the script stops at the first failure.
