@@ -195,7 +195,8 @@ rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
 /* Upper bound in bytes on the device memory the tile renderer's workspace may
  * take on this scene (0 = none, the default).  A batch whose workspace would
  * be larger is halved, like one that does not fit free device memory; results
- * do not depend on the batch shape.  For GPUs shared with other work. */
+ * do not depend on the batch shape.  A workspace that is already larger than
+ * the new bound is released at once.  For GPUs shared with other work. */
 rt_status rt_scene_set_workspace_limit(rt_scene *scene, uint64_t max_bytes);
 /* Bytes of workspace one camera sample in flight takes at these settings
  * (two ray queues of LightSampleRays+1 rays and hits, per-vertex terms for

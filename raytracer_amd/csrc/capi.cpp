@@ -220,8 +220,7 @@ rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
 
 rt_status rt_scene_set_workspace_limit(rt_scene *scene, uint64_t max_bytes) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
-    scene->impl->ws_byte_limit = (size_t)max_bytes;
-    return RT_OK;
+    return rt::scene_set_workspace_limit(*scene->impl, (size_t)max_bytes);
 }
 
 uint64_t rt_workspace_bytes_per_path(int32_t light_sample_rays, int32_t bounce_limit) {

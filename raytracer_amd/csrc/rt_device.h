@@ -129,6 +129,8 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
 rt_status scene_set_tables(Scene &sc, const double *cam, int32_t n_cam, const double *lig, int32_t n_lig);
 rt_status scene_set_texture(Scene &sc, int32_t slot, const uint8_t *rgba, int32_t w, int32_t h);
 void scene_destroy(Scene *sc);
+// Sets the byte bound of the path workspace; a workspace already larger is released.
+rt_status scene_set_workspace_limit(Scene &sc, size_t max_bytes);
 
 rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uint32_t *d_n,
                        rt_hit *d_hits, int mode, unsigned long long *d_counters,

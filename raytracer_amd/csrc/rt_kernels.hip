@@ -1044,6 +1044,19 @@ void workspace_free(Scene &sc) {
     sc.ws_paths = 0;
 }
 
+rt_status scene_set_workspace_limit(Scene &sc, size_t max_bytes) {
+    std::lock_guard<std::mutex> lock(sc.render_mu);
+    sc.ws_byte_limit = max_bytes;
+    if (max_bytes && sc.ws_block_bytes > max_bytes) {
+        DeviceGuard guard(sc.device);
+        if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+        // the last call that used the workspace may still be running on its stream
+        if (sc.ws_done) HIP_TRY(hipEventSynchronize(sc.ws_done));
+        workspace_free(sc);
+    }
+    return RT_OK;
+}
+
 void scene_destroy(Scene *sc) {
     if (!sc) return;
     DeviceGuard guard(sc->device);

@@ -247,6 +247,10 @@ def test_batch_shrinks_when_the_workspace_does_not_fit(cornell_pair):
     assert st["rays"] > W * H * 4
     assert st["kernel_launches"] > 6 * (W * H * 4 * per_path // (40 << 20))   # many batches
     assert torch.equal(rgba_a, rgba_b)
+    # lowering the limit below what the scene holds releases the workspace at once
+    held = torch.cuda.mem_get_info()[0]
+    scene2.set_workspace_limit(8 << 20)
+    assert torch.cuda.mem_get_info()[0] >= held + (16 << 20)
     # a limit too small for even the smallest batch is an error, not a crash
     scene2.set_workspace_limit(1 << 20)
     scene3 = api.Scene(mesh, bvh, torch.cuda.current_device())
