@@ -1099,6 +1099,27 @@ static DevScene dev_view(const Scene &sc) {
 // Launchers
 // ---------------------------------------------------------------------------
 
+// Zeroes 32-bit words with a kernel of its own.  The render and trace calls do
+// not use hipMemsetAsync for their counters and cursors: a call may be captured
+// into a HIP graph, and on this runtime a captured memset of a few bytes was not
+// carried out again when the graph was replayed (the ray cursor kept its value
+// and the second replay traced nothing), whereas kernel nodes replay as issued.
+__global__ void __launch_bounds__(256)
+k_zero_words(uint32_t *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 0u;
+}
+
+static rt_status zero_words(void *p, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return RT_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_zero_words, dim3((uint32_t)blocks), dim3(256), 0, stream, static_cast<uint32_t *>(p), n);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 // Persistent grid: enough 256-thread blocks to fill every CU at the kernel's
 // occupancy, never more blocks than there are 64-ray chunks.
 static uint32_t trace_grid(const Scene &sc, size_t n) {
@@ -1124,7 +1145,7 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     DeviceGuard guard(sc.device);
     if (!guard.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     uint32_t *cursor = d_cursor ? d_cursor : next_cursor(sc);
-    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
+    { const rt_status zs = zero_words(cursor, sizeof(uint32_t), stream); if (zs != RT_OK) return zs; }
     const DevScene d = dev_view(sc);
     const dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
@@ -1401,12 +1422,27 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
     std::mutex &mu = fixed ? fixed->mu : sc.render_mu;
     hipEvent_t done = fixed ? fixed->done : sc.ws_done;
     std::lock_guard<std::mutex> lock(mu);
-    HIP_TRY(hipStreamWaitEvent(stream, done, 0));
+    // A stream that is being captured into a graph takes no part in the event chain:
+    // an event recorded during capture belongs to the graph and could not be waited
+    // for by a later, uncaptured call.  Replays of such graphs are ordered by the
+    // caller (documented with rt_render_tile_static).
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &status) == hipSuccess)
+            capturing = status == hipStreamCaptureStatusActive;
+        else
+            (void)hipGetLastError();
+    }
+    if (!capturing) HIP_TRY(hipStreamWaitEvent(stream, done, 0));
     struct MarkDone {
         hipEvent_t done;
         hipStream_t stream;
-        ~MarkDone() { (void)hipEventRecord(done, stream); }
-    } mark_done{done, stream};
+        bool skip;
+        ~MarkDone() {
+            if (!skip) (void)hipEventRecord(done, stream);
+        }
+    } mark_done{done, stream, capturing};
 
     // batch shape: whole pixel rows of the tile-linear range x as many samples as fit
     const size_t Lq = (size_t)(L > 0 ? L : 1) + 1;             // queue slots a path can fill per vertex
@@ -1452,12 +1488,17 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
     }
 
     const DevScene d = dev_view(sc);
-    if (progress) HIP_TRY(hipMemsetAsync(w.progress_bins, 0, kProgressBins * sizeof(unsigned long long), stream));
-    else w.path_rays = nullptr;            // the kernels keep no per-path ray counts
-    if (zero_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, pixels * 12, stream));
+    if (progress) {
+        if ((st = zero_words(w.progress_bins, kProgressBins * sizeof(unsigned long long), stream)) != RT_OK) return st;
+    } else {
+        w.path_rays = nullptr;             // the kernels keep no per-path ray counts
+    }
+    if (zero_accum) {
+        if ((st = zero_words(d_accum, pixels * 12, stream)) != RT_OK) return st;
+    }
     if (stats) {
-        HIP_TRY(hipMemsetAsync(w.ray_total, 0, 8, stream));
-        HIP_TRY(hipMemsetAsync(w.trav_counters, 0, 8 * sizeof(unsigned long long), stream));
+        if ((st = zero_words(w.ray_total, 8, stream)) != RT_OK) return st;
+        if ((st = zero_words(w.trav_counters, 8 * sizeof(unsigned long long), stream)) != RT_OK) return st;
     }
     EventPool events;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1495,7 +1536,7 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
             b.n_samp = (uint32_t)ns;
             const dim3 block(256), grid((b.P + 255) / 256);
             const size_t qcap = (size_t)b.P * (size_t)((L > 0 ? L : 1) + 1);
-            HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)(B + 3) * sizeof(uint32_t), stream));
+            if ((st = zero_words(w.counts, (size_t)(B + 3) * sizeof(uint32_t), stream)) != RT_OK) return st;
             hipLaunchKernelGGL(k_raygen, grid, block, 0, stream, d, pp, b, w);
             if ((st = timed_trace(w.rays[0], b.P, w.counts + 0, w.hits[0])) != RT_OK) return st;
             for (int k = 0; k <= B; ++k) {
@@ -1506,7 +1547,7 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
             hipLaunchKernelGGL(k_finish, grid, block, 0, stream, d, pp, b, w, (B + 1) & 1);
             hipLaunchKernelGGL(k_accumulate, dim3((b.n_pix + 255) / 256), block, 0, stream, b, w.radiance, d_accum);
             if (stats) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, w.counts, B + 2, w.ray_total);
-            if (progress)
+            if (progress && w.path_rays)
                 hipLaunchKernelGGL(k_progress_bins, grid, block, 0, stream, pp, b, w.path_rays, progress->step,
                                    progress->n_bins, w.progress_bins);
             HIP_TRY(hipGetLastError());

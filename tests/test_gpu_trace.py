@@ -380,3 +380,28 @@ def test_trace_calls_from_two_threads_on_two_streams(soup20k):
         want = alone[i].view(np.uint32).reshape(-1, 4)
         for k in (0, 17, 39):
             assert np.array_equal(d_hits[i][k].cpu().numpy().view(np.uint32), want), (i, k)
+
+
+def test_trace_call_captured_into_a_graph_replays(soup20k):
+    """rt_trace_rays_device allocates nothing and never synchronises, so it can be
+    captured into a HIP graph; every replay must trace the rays again (the ray
+    cursor is reset by a kernel of the call, not by a memset node)."""
+    import torch
+    _, _, _, scene, _ = soup20k
+    rays = random_rays(150_000, seed=41)
+    want = {m: scene.trace_rays(rays, mode=m)[0] for m in (api.MODE_STRICT_F32, api.MODE_FAST_F32)}
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
+    for mode, ref in want.items():
+        d_hits = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            scene.trace_rays_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), mode=mode,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            d_hits.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            got = d_hits.cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mode

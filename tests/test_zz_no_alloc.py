@@ -83,3 +83,37 @@ def test_static_workspace_limit_is_an_error(product_lib, gpu_device):
     p2 = api.pass_from_dict(scenes.make_pass_dict(side2, side2, CORNELL_CAM, spp=2, bounces=4,
                                                   light_samples=1, intensity=100.0, seed=1))
     _both(scene, p2, api.MODE_STRICT_F32)
+
+
+def test_static_workspace_call_under_graph_capture(product_lib, gpu_device):
+    """What the entry point is for: the whole tile render is captured into a HIP
+    graph (a capture forbids allocation and host synchronisation) and replayed;
+    every replay gives the bytes of the allocating call."""
+    import torch
+    sc = cornell()
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 6, 16)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    p = _pass(62, 124, 62, 62, 4, 6, 3, seed=3)
+    n = p.width * p.height
+    acc_ref = torch.zeros((n * 3,), dtype=torch.float32, device="cuda")
+    img_ref = torch.zeros((n * 4,), dtype=torch.uint8, device="cuda")
+    scene.render_tile_device(p, acc_ref.data_ptr(), img_ref.data_ptr(),
+                             stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    acc = torch.zeros((n * 3,), dtype=torch.float32, device="cuda")
+    img = torch.zeros((n * 4,), dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        scene.render_tile_static(p, acc.data_ptr(), img.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        img.zero_()
+        acc.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(img, img_ref)
+        assert torch.equal(acc.view(torch.int32), acc_ref.view(torch.int32))
+    # an ordinary call after the capture still works (the event chain was left alone)
+    _both(scene, p, api.MODE_STRICT_F32)
