@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--leaf", type=int, default=8)
     ap.add_argument("--mode", default="fast")
-    ap.add_argument("--tune", default="")
+    ap.add_argument("--tune", default="", help="stack,refill,blocks_per_cu,descend_min,leaf_min[;...]: several = sweep")
     args = ap.parse_args()
     import torch
     from raytracer_amd import api, scenes
@@ -28,8 +28,9 @@ def main():
     mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
     bvh = api.Bvh.build(mesh, True, args.leaf, 40)
     scene = api.Scene(mesh, bvh, 0)
-    if args.tune:
-        scene.set_tuning(*[int(x) for x in args.tune.split(",")])
+    tunes = [t for t in args.tune.split(";") if t]
+    if len(tunes) == 1:
+        scene.set_tuning(*[int(x) for x in tunes[0].split(",")])
     W, H = 3840, 2160
     tl = scenes.tiles(W, H, 16)
     px = sum(t[3] * t[4] for t in tl)
@@ -40,6 +41,13 @@ def main():
         W, H, sc["camera"], spp=args.spp, bounces=4, light_samples=1, intensity=6.0, seed=1,
         x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid)) for (tid, x, y, w, h) in tl]
     stream = torch.cuda.current_stream().cuda_stream
+    if len(tunes) > 1:   # sweep: best of three uncounted frames per setting
+        for t in tunes:
+            scene.set_tuning(*[int(x) for x in t.split(",")])
+            best = min(scene.render_tiles_device(passes, d_accum.data_ptr(), d_rgba.data_ptr(), mode=mode,
+                                                 stream=stream, want_stats=True)["kernel_ms"] for _ in range(3))
+            print(f"tune {t:20s} kernel_ms {best:.2f}", flush=True)
+        return
     for counted in (False, True):
         scene.set_counters(counted)
         st = scene.render_tiles_device(passes, d_accum.data_ptr(), d_rgba.data_ptr(), mode=mode,
