@@ -318,6 +318,28 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 constexpr int kStackTotal = kFastStackEntries;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// The three plane pairs (near, far) of one child box, from plane offsets to slab
+// distances: decode with one fused multiply-add per pair (offset * step + frame
+// origin), then the reference's (bound - origin) * invDir.  Every instruction
+// works on a (near, far) pair and broadcasts one half of a register pair that
+// holds two different scalars, selected by op_sel.  The trailing wait state is
+// the one the compiler puts between a packed result and an unpacked reader.
+__device__ __forceinline__ void slab_planes(f2 &tx, f2 &ty, f2 &tz, f2 f_oxy, f2 f_ozsx, f2 f_syz,
+                                            f2 r_oxy, f2 r_ozix, f2 r_iyz) {
+    asm("v_pk_fma_f32 %0, %0, %4, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %2, %5, %4 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %6 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %1, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %2, %7 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %0, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %1, %1, %8 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %2, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "s_nop 0"
+        : "+v"(tx), "+v"(ty), "+v"(tz)
+        : "v"(f_oxy), "v"(f_ozsx), "v"(f_syz), "v"(r_oxy), "v"(r_ozix), "v"(r_iyz));
+}
+
 template <bool COUNT, int kStackLds>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
@@ -337,7 +359,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     uint2 spill[kStackSpill];
     bool busy = false;           // this lane holds a ray
     RayFeed feed;
-    float r_ox = 0, r_oy = 0, r_oz = 0, r_ix = 0, r_iy = 0, r_iz = 0;   // origin and inverse direction
+    // origin and inverse direction, as the register pairs the packed slab step reads:
+    // (origin x, origin y), (origin z, 1/dir x), (1/dir y, 1/dir z)
+    f2 r_oxy{0, 0}, r_ozix{0, 0}, r_iyz{0, 0};
     float h_t = 0;               // closest hit so far
     int32_t h_pos = -1;
     // where the lane stands, in the form of a child reference: an interior record
@@ -392,8 +416,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
-                r_ox = a.x; r_oy = a.y; r_oz = a.z;
-                r_ix = 1.0f / b.x; r_iy = 1.0f / b.y; r_iz = 1.0f / b.z;   // ray.go:33-37
+                r_oxy.x = a.x; r_oxy.y = a.y; r_ozix.x = a.z;
+                r_ozix.y = 1.0f / b.x; r_iyz.x = 1.0f / b.y; r_iyz.y = 1.0f / b.z;   // ray.go:33-37
                 h_t = a.w;
                 h_pos = -1;
                 my_park[0 * 256] = 0.0f;
@@ -430,30 +454,32 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // fused multiply-add each (byte -> float conversions are single
             // instructions), and the reference's slab arithmetic
             // (bound - origin) * invDir on the decoded planes, two planes per
-            // packed instruction
-            const f2 fo_x{q0.x, q0.x}, fo_y{q0.y, q0.y}, fo_z{q0.z, q0.z};
-            const f2 fs_x{q0.w, q0.w}, fs_y{q1.x, q1.x}, fs_z{q1.y, q1.y};
-            // the plane a ray meets first on an axis is the lower one when it
+            // packed instruction.
+            // The plane a ray meets first on an axis is the lower one when it
             // travels up that axis and the upper one otherwise: pick the near and
             // far plane words once per record (the sign of the inverse direction
             // is the direction's, also for +-0), so that no per-child min/max of
             // the two slab distances is needed
-            const bool nx = r_ix < 0, ny = r_iy < 0, nz = r_iz < 0;
+            const bool nx = r_ozix.y < 0, ny = r_iyz.x < 0, nz = r_iyz.y < 0;
             const uint32_t lox = (uint32_t)f2i(q1.z), loy = (uint32_t)f2i(q1.w), loz = (uint32_t)f2i(q2.x);
             const uint32_t hix = (uint32_t)f2i(q2.y), hiy = (uint32_t)f2i(q2.z), hiz = (uint32_t)f2i(q2.w);
             const uint32_t plx = nx ? hix : lox, ply = ny ? hiy : loy, plz = nz ? hiz : loz;   // near
             const uint32_t phx = nx ? lox : hix, phy = ny ? loy : hiy, phz = nz ? loz : hiz;   // far
-            const f2 ox{r_ox, r_ox}, oy{r_oy, r_oy}, oz{r_oz, r_oz};
-            const f2 ix{r_ix, r_ix}, iy{r_iy, r_iy}, iz{r_iz, r_iz};
+            // Packed operands are register pairs as they were loaded; which half an
+            // instruction broadcasts is said by its op_sel bits, so no pair has to
+            // be assembled with moves: frame origin x|y = (q0.x,q0.y), origin z and
+            // step x = (q0.z,q0.w), step y|z = (q1.x,q1.y); the ray likewise
+            // (origin x|y), (origin z, 1/dir x), (1/dir y|z).
+            const f2 f_oxy{q0.x, q0.y}, f_ozsx{q0.z, q0.w}, f_syz{q1.x, q1.y};
             float key[4];
             uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
 #define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
 #define RT_SLAB(k)                                                                          \
             {                                                                               \
-                const f2 bx = __builtin_elementwise_fma(f2{RT_BYTE(plx, k), RT_BYTE(phx, k)}, fs_x, fo_x); \
-                const f2 by = __builtin_elementwise_fma(f2{RT_BYTE(ply, k), RT_BYTE(phy, k)}, fs_y, fo_y); \
-                const f2 bz = __builtin_elementwise_fma(f2{RT_BYTE(plz, k), RT_BYTE(phz, k)}, fs_z, fo_z); \
-                const f2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;     \
+                f2 tx{RT_BYTE(plx, k), RT_BYTE(phx, k)};                                    \
+                f2 ty{RT_BYTE(ply, k), RT_BYTE(phy, k)};                                    \
+                f2 tz{RT_BYTE(plz, k), RT_BYTE(phz, k)};                                    \
+                slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);        \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
                 const bool hit = tn <= tf && tn <= h_t && tf > 0 && ref[k] != kLeafBit;      \
@@ -498,9 +524,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
             // the full ray and hit only exist here
             Ray<float> r;
-            r.ox = r_ox; r.oy = r_oy; r.oz = r_oz;
+            r.ox = r_oxy.x; r.oy = r_oxy.y; r.oz = r_ozix.x;
             r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
-            r.ix = r_ix; r.iy = r_iy; r.iz = r_iz;
+            r.ix = r_ozix.y; r.iy = r_iyz.x; r.iz = r_iyz.y;
             Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
             bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
             if (COUNT && tested) c_test++;
