@@ -244,18 +244,35 @@ struct WideBuilder {
                 if (ok || !std::isfinite(s)) { step[a] = s; break; }
             }
         }
+        // An unused slot carries an inverted box: lower planes at offset 255, upper
+        // planes at offset 0.  On an axis where offset 255 decodes above offset 0 the
+        // slab interval of such a box is empty for every ray, so the traversal needs
+        // no "slot in use" test.  A record whose children are all one point has no
+        // such axis yet: widen its x step until it has one (its children sit at
+        // offset 0 on that axis and stay where they are).
+        if (n < 4) {
+            bool strict_axis = false;
+            for (int a = 0; a < 3; ++a)
+                if (std::fmaf(255.0f, step[a], origin[a]) > origin[a]) strict_axis = true;
+            if (!strict_axis) {
+                float s = std::fabs(origin[0]) * 1e-9f;
+                if (!(s > step[0])) s = step[0];
+                while (!(std::fmaf(255.0f, s, origin[0]) > origin[0]) && std::isfinite(s)) s *= 2.0f;
+                step[0] = s;
+            }
+        }
         float *p = &recs[(size_t)rec * rtc::kWideFloats];
         p[0] = origin[0]; p[1] = origin[1]; p[2] = origin[2];
         p[3] = step[0]; p[4] = step[1]; p[5] = step[2];
         uint32_t planes[6] = {0, 0, 0, 0, 0, 0};   // lo.x lo.y lo.z hi.x hi.y hi.z, child c in byte c
-        for (int i = 0; i < n; ++i)
+        for (int i = 0; i < 4; ++i)
             for (int a = 0; a < 3; ++a) {
-                planes[a] |= (uint32_t)qlo[i][a] << (8 * i);
-                planes[3 + a] |= (uint32_t)qhi[i][a] << (8 * i);
+                planes[a] |= (uint32_t)(i < n ? qlo[i][a] : 255) << (8 * i);
+                planes[3 + a] |= (uint32_t)(i < n ? qhi[i][a] : 0) << (8 * i);
             }
         for (int j = 0; j < 6; ++j) p[6 + j] = rtc::i2f((int32_t)planes[j]);
         for (int i = 0; i < 4; ++i) {
-            uint32_t ref = rtc::kLeafBit;            // unused slot: no triangles, never entered
+            uint32_t ref = rtc::kLeafBit;            // unused slot: a leaf of no triangles behind an inverted box
             if (i < n) {
                 const BNode c = bin[(size_t)kids[i]];
                 ref = c.left < 0 ? leaf_ref(c) : emit(kids[i], depth + 1);

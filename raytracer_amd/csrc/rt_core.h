@@ -279,7 +279,8 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 const float tn = fmaxf(fmaxf(tna[0], tna[1]), tna[2]);
                 const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);
                 ref[k] = (uint32_t)f2i(q[12 + k]);
-                const bool hit = tn <= tf && tn <= h.t && tf > 0 && ref[k] != kLeafBit;
+                // an unused slot has an inverted box (tn > tf) and needs no test of its own
+                const bool hit = tn <= tf && tn <= h.t && tf > 0;
                 key[k] = hit ? tn : kF32Inf;
                 n_hit += hit ? 1 : 0;
             }

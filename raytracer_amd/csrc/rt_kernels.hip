@@ -377,8 +377,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         else if (sp < kStackTotal) spill[sp - kStackLds] = e;
         sp++;   // deeper than both levels cannot happen: a wide tree whose depth x 3 exceeds the stack is not built
     };
-    // Stands the lane on `ref`: an interior record, or a leaf (never empty: unused
-    // slots are never hit and empty leaves are not stored).
+    // Stands the lane on `ref`: an interior record, or a leaf.
     auto stand_on = [&](uint32_t ref) { where = ref; };
     // Next stacked entry that can still hold a closer hit; false when the ray is
     // finished.  The LDS slot is read unconditionally (index clamped) and replaced
@@ -482,7 +481,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);        \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                const bool hit = tn <= tf && tn <= h_t && tf > 0 && ref[k] != kLeafBit;      \
+                const bool hit = tn <= tf && tn <= h_t && tf > 0;   /* unused slot: inverted box */ \
                 key[k] = hit ? tn : kF32Inf;                                                \
             }
             RT_SLAB(0)
@@ -519,16 +518,23 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool two = tri_n > 1;
             const f4 *qa = s.tris + 3 * (size_t)tri_i;
             const f4 *qb = qa + (two ? 3 : 0);
-            const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
+            f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
             const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-            if (COUNT) { c_fetch += two ? 2 : 1; c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
+            // all six loads are issued here, together: left alone the compiler moves
+            // the first triangle's into the branch that tests it and splits them up
+            asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w));
+            asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w));
+            asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
+            if (COUNT) { c_fetch += two ? 2 : (tri_n > 0 ? 1 : 0); c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
             // the full ray and hit only exist here
             Ray<float> r;
             r.ox = r_oxy.x; r.oy = r_oxy.y; r.oz = r_ozix.x;
             r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
             r.ix = r_ozix.y; r.iy = r_iyz.x; r.iz = r_iyz.y;
             Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
-            bool tested = tri_test<float, true>(r, a0, a1, a2, tri_i, h);
+            // (a leaf of no triangles is what an unused slot refers to; its inverted
+            // box lets a ray in only when rounding collapses the box's extent)
+            bool tested = tri_n > 0 && tri_test<float, true>(r, a0, a1, a2, tri_i, h);
             if (COUNT && tested) c_test++;
             if (two) {
                 tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);

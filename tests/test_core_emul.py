@@ -212,6 +212,29 @@ def test_ordered_traversal_finds_the_same_hits(product_lib, oracle, emul, n, lea
         assert 56 * int(cnt[1]) + 48 * int(cnt[3]) < 56 * c["nodes_visited"] + 48 * c["tris_fetched"]
 
 
+def test_ordered_traversal_with_point_triangles(product_lib, oracle, emul):
+    """Records whose children are all one point (triangles collapsed to a point,
+    some of them identical) have no extent to quantise; the unused slots of such
+    records must still keep rays out, or at least cost nothing but work."""
+    sc = scenes.soup(600, seed=31)
+    v = sc["verts"].reshape(-1, 3, 3).copy()
+    v[100:140] = v[100:140, :1, :]                       # 40 point triangles
+    v[140:150] = v[140, 0][None, None, :]                # 10 of them on one point
+    v[150:153] = np.float32(0.0)                         # and 3 at the origin
+    sc = dict(sc, verts=np.ascontiguousarray(v.reshape(-1, 9)))
+    bvh = api.Bvh.build(product_mesh(sc), True, 2, 24)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    rays = random_rays(6000, seed=9)
+    rays["origin"][::3] *= np.float32(1e6)               # far origins: extents below rounding
+    hits, cnt = emul_trace_fast(emul, bvh, rays)
+    r6, tmax = rays6(rays)
+    ref = osc.trace_rays(r6, tmax)
+    assert np.array_equal(hits["tri_pos"], ref["tri"])
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    rec, _ = bvh.flatten_ordered()
+    assert np.isfinite(rec[:, 0:6]).all() and (rec[:, 3:6] > 0).all()
+
+
 def _decode_wide(rec):
     """Child boxes of 64-byte ordered-traversal records: (n, 4, 3) lower and
     upper planes, decoded like the traversal does, fma(offset, step, origin)."""
@@ -251,6 +274,17 @@ def test_ordered_records_layout(product_lib):
     # every record but the root is referenced exactly once; used slots come first
     assert sorted(refs[interior].tolist()) == list(range(1, rec.shape[0]))
     assert (np.diff(unused.astype(int), axis=1) >= 0).all()
+    # an unused slot carries an inverted box (lower planes at offset 255, upper at 0),
+    # and its record has an axis on which offset 255 decodes above offset 0: the slab
+    # interval of that box is empty, which is all that keeps rays out of the slot
+    planes = rec[:, 6:12].view(np.uint32)
+    k = np.arange(4, dtype=np.uint32)[None, :, None]
+    lo_q = (planes[:, None, 0:3] >> (8 * k)) & 0xFF
+    hi_q = (planes[:, None, 3:6] >> (8 * k)) & 0xFF
+    assert unused.any()
+    assert (lo_q[unused] == 255).all() and (hi_q[unused] == 0).all()
+    top = (255.0 * rec[:, 3:6].astype(np.float64) + rec[:, 0:3].astype(np.float64)).astype(np.float32)
+    assert ((top > rec[:, 0:3]).any(axis=1))[unused.any(axis=1)].all()
     # steps are positive and finite; decoded leaf boxes contain their triangles
     step = rec[:, 3:6]
     assert np.isfinite(step).all() and (step > 0).all()

@@ -202,6 +202,30 @@ def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul, oracle):
     assert 56 * st["nodes_visited"] + 48 * st["tris_fetched"] < 56 * c["nodes_visited"] + 48 * c["tris_fetched"]
 
 
+def test_fast_mode_with_point_triangles(product_lib, emul, gpu_device):
+    """Triangles collapsed to points (some identical) give records without
+    extent; unused slots of such records carry an inverted box that rounding can
+    collapse for far-away origins.  The kernel and its lane-serial CPU form
+    must still agree bit for bit, counters included."""
+    sc = scenes.soup(600, seed=31)
+    v = sc["verts"].reshape(-1, 3, 3).copy()
+    v[100:140] = v[100:140, :1, :]
+    v[140:150] = v[140, 0][None, None, :]
+    v[150:153] = np.float32(0.0)
+    sc = dict(sc, verts=np.ascontiguousarray(v.reshape(-1, 9)))
+    mesh = product_mesh(sc)
+    bvh = api.Bvh.build(mesh, True, 2, 24)
+    scene = api.Scene(mesh, bvh, gpu_device)
+    rays = random_rays(50000, seed=9)
+    rays["origin"][::3] *= np.float32(1e6)
+    hits, st = scene.trace_rays(rays, mode=api.MODE_FAST_F32, counters=True)
+    cpu, cnt = _emul_fast(emul, bvh, rays)
+    assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
+    assert [st["rays"], st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]] == cnt.tolist()
+    strict, _ = scene.trace_rays(rays, mode=api.MODE_STRICT_F32)
+    assert np.array_equal(hits["tri_pos"], strict["tri_pos"])
+
+
 def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
     """Rays along quad diagonals and box faces: exact t ties between the two
     triangles of a wall resolve to the earlier array position, as in the
