@@ -54,11 +54,15 @@ namespace rt {
 // wave helpers (wave64)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+// Lanes of the wave for which `p` holds.  (HIP's __ballot takes an int: a bool
+// argument costs a select to 0/1 and a compare back to a mask on every call.)
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // Wave-aggregated queue append: one atomic per wave, slots in lane order.
 __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
-    const uint64_t m = __ballot(want);
+    const uint64_t m = wave_ballot(want);
     if (m == 0) return 0;
     const int leader = __ffsll((unsigned long long)m) - 1;
     uint32_t base = 0;
@@ -77,7 +81,7 @@ __device__ __forceinline__ uint32_t block_append(uint32_t *counter, bool want, i
     __shared__ uint32_t s_base[2];
     const int slot = call & 1;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint64_t m = __ballot(want);
+    const uint64_t m = wave_ballot(want);
     if (lane_id() == 0) s_cnt[slot][wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -172,7 +176,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             *reinterpret_cast<f4 *>(hits + idx) = out;
             idx = -1;
         }
-        uint64_t active = __ballot(idx >= 0);
+        uint64_t active = wave_ballot(idx >= 0);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
             const int32_t mine = feed_take(feed, next, n, ~active);
             if (mine >= 0) {
@@ -187,7 +191,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
                 leaf_n = 0;
                 idx = mine;
             }
-            active = __ballot(idx >= 0);
+            active = wave_ballot(idx >= 0);
         }
         if (active == 0) {
             if (feed.exhausted && feed.pos >= feed.end) break;
@@ -199,9 +203,9 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         // while others wait on a leaf
         for (;;) {
             const bool walking = idx >= 0 && node < s.n_nodes && leaf_n == 0;
-            const uint64_t m_walk = __ballot(walking);
+            const uint64_t m_walk = wave_ballot(walking);
             if (m_walk == 0) break;
-            if ((int)__popcll(m_walk) < descend_min && __ballot(idx >= 0 && leaf_n > 0) != 0) break;
+            if ((int)__popcll(m_walk) < descend_min && wave_ballot(idx >= 0 && leaf_n > 0) != 0) break;
             if (!walking) continue;
             f4 lo, hi;
             if (TOP) {
@@ -255,10 +259,10 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         // leaf, or when fewer than leaf_min do while enough lanes wait to walk
         for (;;) {
             const bool in_leaf = idx >= 0 && leaf_n > 0;
-            const uint64_t m_leaf = __ballot(in_leaf);
+            const uint64_t m_leaf = wave_ballot(in_leaf);
             if (m_leaf == 0) break;
             if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(__ballot(idx >= 0 && node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
+                (int)__popcll(wave_ballot(idx >= 0 && node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
             if (!in_leaf) continue;
             // two triangles per step, fetched together so that their loads overlap,
             // tested in array order
@@ -357,18 +361,21 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     const uint32_t lane = lane_id();
     uint2 *my_stack = lds_stack + (threadIdx.x >> 6) * (kStackLds * 64) + lane;
     uint2 spill[kStackSpill];
-    bool busy = false;           // this lane holds a ray
     RayFeed feed;
     // origin and inverse direction, as the register pairs the packed slab step reads:
     // (origin x, origin y), (origin z, 1/dir x), (1/dir y, 1/dir z)
     f2 r_oxy{0, 0}, r_ozix{0, 0}, r_iyz{0, 0};
     float h_t = 0;               // closest hit so far
     int32_t h_pos = -1;
-    // where the lane stands, in the form of a child reference: an interior record
-    // index, or leaf bit | triangles left << 24 | next triangle
-    uint32_t where = 0;
+    // The lane's whole state is where it stands, in the form of a child reference:
+    // an interior record index (>= 0 as a signed number), or leaf bit | triangles
+    // left << 24 | next triangle (below -2), or one of two values no leaf can
+    // have: kRefDone (-1), its ray is finished and waits to be written out, and
+    // kLaneIdle (-2), it holds no ray.  Every vote of the wave is then ONE compare
+    // of this register.
+    constexpr uint32_t kLaneIdle = 0xFFFFFFFEu;
+    uint32_t where = kLaneIdle;
     int32_t sp = 0;
-    bool alive = false;          // this lane's ray still has work
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
 
     auto push = [&](uint32_t ref, float tn) {
@@ -379,11 +386,11 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     };
     // Stands the lane on `ref`: an interior record, or a leaf.
     auto stand_on = [&](uint32_t ref) { where = ref; };
-    // Next stacked entry that can still hold a closer hit; false when the ray is
-    // finished.  The LDS slot is read unconditionally (index clamped) and replaced
+    // Next stacked entry that can still hold a closer hit; kRefDone when the ray
+    // is finished.  The LDS slot is read unconditionally (index clamped) and replaced
     // from the spill array only when the entry lives there, so that both accesses
     // keep their own address space.
-    auto pop_next = [&]() -> bool {
+    auto pop_next = [&]() {
         while (sp > 0) {
             sp--;
             uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
@@ -391,15 +398,15 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (sp >= kStackLds) e = spill[sp - kStackLds];
             if (i2f((int32_t)e.y) <= h_t) {
                 stand_on(e.x);
-                return true;
+                return;
             }
         }
-        return false;
+        where = kRefDone;
     };
 
     for (;;) {
         // retire finished rays, refill idle lanes
-        if (busy && !alive) {
+        if (where == kRefDone) {
             f4 out;
             out.x = i2f(h_pos);
             out.y = h_t;
@@ -407,9 +414,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             out.w = my_park[1 * 256];
             const int32_t idx = f2i(my_park[2 * 256]);
             *reinterpret_cast<f4 *>(hits + idx) = out;
-            busy = false;
+            where = kLaneIdle;
         }
-        uint64_t active = __ballot(busy);
+        uint64_t active = wave_ballot(where != kLaneIdle);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
             const int32_t mine = feed_take(feed, next, n, ~active);
             if (mine >= 0) {
@@ -426,11 +433,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 my_park[4 * 256] = b.y;
                 my_park[5 * 256] = b.z;
                 sp = 0;
-                busy = true;
-                alive = true;
                 stand_on(s.fast_root);
             }
-            active = __ballot(busy);
+            active = wave_ballot(where != kLaneIdle);
         }
         if (active == 0) {
             if (feed.exhausted && feed.pos >= feed.end) break;
@@ -441,14 +446,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         // once fewer than descend_min lanes still descend while others wait on a
         // leaf: one long descent must not idle the wave.
         for (;;) {
-            const bool descending = busy && alive && (where & kLeafBit) == 0;
-            const uint64_t m_desc = __ballot(descending);
+            const bool descending = (int32_t)where >= 0;
+            const uint64_t m_desc = wave_ballot(descending);
             if (m_desc == 0) break;
-            if ((int)__popcll(m_desc) < descend_min && __ballot(busy && alive && (where & kLeafBit) != 0) != 0) break;
-            if (!descending) continue;
+            if ((int)__popcll(m_desc) < descend_min && wave_ballot((int32_t)where < -2) != 0) break;
+            if (descending) {
             const f4 *q = s.wide + 4 * (size_t)where;
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) { c_nodes++; c_box += 4; if ((__ballot(true) & lanemask_lt()) == 0) c_wa++; }
+            if (COUNT) { c_nodes++; c_box += 4; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // frame of the record, then per child: decode the six planes with one
             // fused multiply-add each (byte -> float conversions are single
             // instructions), and the reference's slab arithmetic
@@ -493,13 +498,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             wide_sort4(key, ref);
             // missed children carry +inf and sort last
             if (!(key[0] < kF32Inf)) {
-                alive = pop_next();
+                pop_next();
             } else {
                 // farthest first, so that the nearest of the rest is popped first
                 if (key[3] < kF32Inf) push(ref[3], key[3]);
                 if (key[2] < kF32Inf) push(ref[2], key[2]);
                 if (key[1] < kF32Inf) push(ref[1], key[1]);
                 stand_on(ref[0]);
+            }
             }
         }
         // phase B: lanes holding a leaf test its triangles in array order, two
@@ -508,12 +514,12 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         // holds a leaf, or when fewer than leaf_min do while enough lanes wait to
         // descend (the few keep their place in the leaf for the next round).
         for (;;) {
-            const bool in_leaf = busy && alive && (where & kLeafBit) != 0;
-            const uint64_t m_leaf = __ballot(in_leaf);
+            const bool in_leaf = (int32_t)where < -2;
+            const uint64_t m_leaf = wave_ballot(in_leaf);
             if (m_leaf == 0) break;
             if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(__ballot(busy && alive && (where & kLeafBit) == 0)) >= descend_min) break;
-            if (!in_leaf) continue;
+                (int)__popcll(wave_ballot((int32_t)where >= 0)) >= descend_min) break;
+            if (in_leaf) {
             const int32_t tri_i = (int32_t)(where & 0xFFFFFFu), tri_n = (int32_t)((where >> 24) & 0x7Fu);
             const bool two = tri_n > 1;
             const f4 *qa = s.tris + 3 * (size_t)tri_i;
@@ -525,7 +531,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w));
             asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w));
             asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
-            if (COUNT) { c_fetch += two ? 2 : (tri_n > 0 ? 1 : 0); c_lb++; if ((__ballot(true) & lanemask_lt()) == 0) c_wb++; }
+            if (COUNT) { c_fetch += two ? 2 : (tri_n > 0 ? 1 : 0); c_lb++; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wb++; }
             // the full ray and hit only exist here
             Ray<float> r;
             r.ox = r_oxy.x; r.oy = r_oxy.y; r.oz = r_ozix.x;
@@ -547,9 +553,10 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             }
             h_t = h.t;
             if (tri_n <= 2) {
-                alive = pop_next();
+                pop_next();
             } else {
                 where = kLeafBit | ((uint32_t)(tri_n - 2) << 24) | (uint32_t)(tri_i + 2);
+            }
             }
         }
     }
