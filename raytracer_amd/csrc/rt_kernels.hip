@@ -162,7 +162,10 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
     RayFeed feed;
     Ray<Real> r;
     Hit<Real> h;
-    int32_t node = 0, leaf_a = 0, leaf_n = 0;   // next node in preorder; triangles left in the passed leaf
+    // next node in preorder; triangles left in the passed leaf.  A lane without a ray
+    // stands past the last node with no triangles left, like a lane whose ray has just
+    // finished, so the votes below need not look at idx.
+    int32_t node = 0x7fffffff, leaf_a = 0, leaf_n = 0;
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
 
     for (;;) {
@@ -202,10 +205,10 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         // passed leaf; the phase ends once fewer than descend_min lanes still walk
         // while others wait on a leaf
         for (;;) {
-            const bool walking = idx >= 0 && node < s.n_nodes && leaf_n == 0;
+            const bool walking = node < s.n_nodes && leaf_n == 0;
             const uint64_t m_walk = wave_ballot(walking);
             if (m_walk == 0) break;
-            if ((int)__popcll(m_walk) < descend_min && wave_ballot(idx >= 0 && leaf_n > 0) != 0) break;
+            if ((int)__popcll(m_walk) < descend_min && wave_ballot(leaf_n > 0) != 0) break;
             if (!walking) continue;
             f4 lo, hi;
             if (TOP) {
@@ -258,11 +261,11 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         // phase B: the leaf's triangles, in array order; ends when no lane holds a
         // leaf, or when fewer than leaf_min do while enough lanes wait to walk
         for (;;) {
-            const bool in_leaf = idx >= 0 && leaf_n > 0;
+            const bool in_leaf = leaf_n > 0;
             const uint64_t m_leaf = wave_ballot(in_leaf);
             if (m_leaf == 0) break;
             if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(wave_ballot(idx >= 0 && node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
+                (int)__popcll(wave_ballot(node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
             if (!in_leaf) continue;
             // two triangles per step, fetched together so that their loads overlap,
             // tested in array order
