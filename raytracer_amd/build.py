@@ -4,6 +4,9 @@ The compile needs no GPU: hipcc cross-compiles for gfx950.  Flags that matter
 for correctness: -ffp-contract=off (the reference's float32 arithmetic is
 never fused and the bit-exact modes depend on it) and
 -fhip-fp32-correctly-rounded-divide-sqrt (IEEE 1/x and sqrt on the device).
+For speed: -fno-slp-vectorize (left on, the vectoriser pairs up the scalar
+arithmetic of the triangle test into packed instructions and spends more moves
+on building the register pairs than the packed instructions save).
 """
 import os
 import subprocess
@@ -21,7 +24,7 @@ HEADERS = ["gomath.h", "json.h", "rt_core.h", "rt_device.h", "rt_internal.h", "b
            os.path.join("..", "..", "include", "rt_backend.h")]
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-pthread",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread",
          "-Wall", "-Wextra"]
 
 

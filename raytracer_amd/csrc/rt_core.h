@@ -184,6 +184,36 @@ RT_HD bool tri_test(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2
     return true;
 }
 
+// The same test with no early exit: every value is computed and the conditions
+// are combined at the end, each in the form the step-by-step version tests it
+// (a NaN fails a comparison in both), so `inside` holds exactly when tri_test
+// would reach its last line with t > 0, and t, u, v are then the same bits.
+// For a wave whose lanes test different triangles the early exits skip nothing
+// (some lane always goes on) and only cost the bookkeeping of nested branches.
+// Returns whether the triangle faces the ray (the counters' "tested").
+template <typename Real>
+RT_HD bool tri_eval(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2, Real &t, Real &u,
+                    Real &v, bool &inside) {
+    const Real nx = (Real)q0.x, ny = (Real)q0.y, nz = (Real)q0.z;
+    const bool facing = !(nx * r.dx + ny * r.dy + nz * r.dz > 0);
+    const Real wx = (Real)q2.y, wy = (Real)q2.z, wz = (Real)q2.w;
+    const Real ex = (Real)q1.z, ey = (Real)q1.w, ez = (Real)q2.x;
+    const Real px = r.dy * wz - r.dz * wy;
+    const Real py = r.dz * wx - r.dx * wz;
+    const Real pz = r.dx * wy - r.dy * wx;
+    const Real det = ex * px + ey * py + ez * pz;
+    const Real invdet = (Real)1.0 / det;
+    const Real tx = r.ox - (Real)q0.w, ty = r.oy - (Real)q1.x, tz = r.oz - (Real)q1.y;
+    u = (tx * px + ty * py + tz * pz) * invdet;
+    const Real qx = ty * ez - tz * ey;
+    const Real qy = tz * ex - tx * ez;
+    const Real qz = tx * ey - ty * ex;
+    v = (r.dx * qx + r.dy * qy + r.dz * qz) * invdet;
+    t = (wx * qx + wy * qy + wz * qz) * invdet;
+    inside = facing & !(det < (Real)0.0001f) & !((u < 0) | (u > 1)) & !((v < 0) | (u + v > 1)) & (t > 0);
+    return facing;
+}
+
 struct Counters {
     uint32_t nodes_visited = 0, box_tests = 0, tris_fetched = 0, tris_tested = 0;
 };

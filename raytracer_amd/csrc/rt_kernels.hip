@@ -535,26 +535,31 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w));
             asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
             if (COUNT) { c_fetch += two ? 2 : (tri_n > 0 ? 1 : 0); c_lb++; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wb++; }
-            // the full ray and hit only exist here
+            // the full ray only exists here
             Ray<float> r;
             r.ox = r_oxy.x; r.oy = r_oxy.y; r.oz = r_ozix.x;
             r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
             r.ix = r_ozix.y; r.iy = r_iyz.x; r.iz = r_iyz.y;
-            Hit<float> h{h_t, 0.0f, 0.0f, h_pos};
-            // (a leaf of no triangles is what an unused slot refers to; its inverted
-            // box lets a ray in only when rounding collapses the box's extent)
-            bool tested = tri_n > 0 && tri_test<float, true>(r, a0, a1, a2, tri_i, h);
-            if (COUNT && tested) c_test++;
-            if (two) {
-                tested = tri_test<float, true>(r, b0, b1, b2, tri_i + 1, h);
-                if (COUNT && tested) c_test++;
+            // both triangles are evaluated side by side without early exits, then
+            // offered to the hit in array order (a triangle is accepted below the
+            // current distance, or at it from an earlier position).  A leaf of no
+            // triangles is what an unused slot refers to; its inverted box lets a ray
+            // in only when rounding collapses the box's extent.
+            float ta, ua, va, tb, ub, vb;
+            bool in_a, in_b;
+            const bool faced_a = tri_eval(r, a0, a1, a2, ta, ua, va, in_a);
+            const bool faced_b = tri_eval(r, b0, b1, b2, tb, ub, vb, in_b);
+            if (COUNT) c_test += (tri_n > 0 && faced_a ? 1u : 0u) + (two && faced_b ? 1u : 0u);
+            const bool take_a = (tri_n > 0) & in_a & ((ta < h_t) | ((ta == h_t) & (tri_i < h_pos)));
+            h_t = take_a ? ta : h_t;
+            h_pos = take_a ? tri_i : h_pos;
+            const bool take_b = two & in_b & ((tb < h_t) | ((tb == h_t) & (tri_i + 1 < h_pos)));
+            h_t = take_b ? tb : h_t;
+            h_pos = take_b ? tri_i + 1 : h_pos;
+            if (take_a | take_b) {
+                my_park[0 * 256] = take_b ? ub : ua;
+                my_park[1 * 256] = take_b ? vb : va;
             }
-            if (h.pos != h_pos) {      // a triangle is accepted at most once
-                my_park[0 * 256] = h.u;
-                my_park[1 * 256] = h.v;
-                h_pos = h.pos;
-            }
-            h_t = h.t;
             if (tri_n <= 2) {
                 pop_next();
             } else {
