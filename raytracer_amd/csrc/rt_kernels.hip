@@ -142,13 +142,17 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 // ---------------------------------------------------------------------------
 
 // TOP: the tree is read through its linked view (DevScene::linked), whose
-// first n_top nodes -- the levels nearest the root, a third of all node
-// fetches -- are copied into LDS by every block: the kernel is bound by the
-// number of per-lane global loads.  Visit order and arithmetic are the same.
-constexpr int kTopNodes = 512;
+// first n_top nodes -- the whole levels nearest the root that fit kTopNodes
+// records, the most fetched nodes of the tree -- are copied into LDS by every
+// block: the kernel is bound by the number of per-lane global loads.  A copy is
+// shared by the 16 waves of a 1024-thread block (64 KB, two blocks per CU); with
+// 256-thread blocks the same LDS held eight copies of a quarter as many nodes.
+// Visit order and arithmetic are the same.
+constexpr int kTopNodes = 2048;
+constexpr int kTopBlock = 1024;
 
 template <typename Real, bool COUNT, bool TOP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TOP ? kTopBlock : 256)
 k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
             unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
@@ -1194,7 +1198,7 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     uint32_t *cursor = d_cursor ? d_cursor : next_cursor(sc);
     { const rt_status zs = zero_words(cursor, sizeof(uint32_t), stream); if (zs != RT_OK) return zs; }
     const DevScene d = dev_view(sc);
-    const dim3 grid(trace_grid(sc, n_host)), block(256);
+    dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
     // wave scheduling thresholds (refill, descend_min, leaf_min): measured optimum per kernel
     const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_wide;
@@ -1220,12 +1224,14 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         // trees that do not fit the ordered-traversal encoding run the reference order
         [[fallthrough]];
     case RT_MODE_STRICT_F32:
+        if (d.linked) { block = dim3(kTopBlock); grid = dim3((grid.x * 256 + kTopBlock - 1) / kTopBlock); }
         if (d_counters)
             { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
             { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         break;
     case RT_MODE_FP64:
+        if (d.linked) { block = dim3(kTopBlock); grid = dim3((grid.x * 256 + kTopBlock - 1) / kTopBlock); }
         if (d_counters)
             { if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
