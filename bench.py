@@ -76,7 +76,11 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=0,
                     help="tiles taken per pull with --dynamic (0 = enough for about 32 M camera samples per call)")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
-    ap.add_argument("--max-paths", type=int, default=0, help="camera samples traced together (0 = default)")
+    ap.add_argument("--max-paths", type=int, default=1 << 28,
+                    help="camera samples traced together (0 = the library's default of 64 M = 24 GB of path "
+                         "workspace; the bench takes 256 M = 96 GB of the GPU's 288 GB: every traversal launch "
+                         "ends with a drain phase, and a 64-spp 4K frame in 2 batches instead of 8 is 2.6 %% faster; "
+                         "a batch that does not fit free memory is halved by the library)")
     ap.add_argument("--pretend-world", type=int, default=0,
                     help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
                          "no collectives (estimates the per-rank time of a larger job)")
@@ -470,6 +474,7 @@ def main():
                        "tiles": len(tile_list),
                        "tile_assignment": "dynamic pull queue" if queue is not None else "block-cyclic",
                        "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
+                       "paths_per_batch": int(args.max_paths) if args.max_paths else 1 << 26,
                        "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
             "roofline": roof,
         }
