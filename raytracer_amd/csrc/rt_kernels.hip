@@ -145,10 +145,11 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 // first n_top nodes -- the whole levels nearest the root that fit kTopNodes
 // records, the most fetched nodes of the tree -- are copied into LDS by every
 // block: the kernel is bound by the number of per-lane global loads.  A copy is
-// shared by the 16 waves of a 1024-thread block (64 KB, two blocks per CU); with
-// 256-thread blocks the same LDS held eight copies of a quarter as many nodes.
+// shared by the 16 waves of a 1024-thread block (80 KB, two blocks per CU fill its
+// 160 KB of LDS); with 256-thread blocks the same LDS held eight copies of a fifth
+// as many nodes.
 // Visit order and arithmetic are the same.
-constexpr int kTopNodes = 2048;
+constexpr int kTopNodes = 2560;
 constexpr int kTopBlock = 1024;
 
 template <typename Real, bool COUNT, bool TOP>
@@ -916,8 +917,8 @@ struct DeviceGuard {
 }  // namespace
 
 // Linked form of the reference-order node array (DevScene::linked): the nodes
-// of the first levels (as many whole levels as fit max_top nodes) are moved to
-// the front, the others keep their preorder behind them, and the implicit
+// of the first levels (as many whole levels as fit max_top nodes, then the first
+// nodes of the next level until max_top is reached) are moved to the front, the others keep their preorder behind them, and the implicit
 // "next node = this one + 1" of the preorder array becomes an explicit link.
 // Returns false when a leaf does not fit the packed encoding (more than 127
 // triangles, or a first triangle beyond 2^24): such trees use the plain array.
@@ -935,11 +936,20 @@ static bool link_nodes(const Bvh &bvh, const std::vector<float> &nodes, int32_t 
     int32_t top_depth = 0, count = 0;      // nodes with depth < top_depth go to the front
     while ((size_t)top_depth < per_depth.size() && count + per_depth[(size_t)top_depth] <= max_top)
         count += per_depth[(size_t)top_depth++];
-    n_top = count;
+    // the room left after the whole levels goes to the first nodes, in preorder, of the next one
+    int32_t extra = (size_t)top_depth < per_depth.size() ? max_top - count : 0;
+    n_top = count + extra;
     std::vector<int32_t> to_new((size_t)nn + 1);
     int32_t next_top = 0, next_deep = n_top;
-    for (int32_t i = 0; i < nn; ++i)
-        to_new[(size_t)i] = bvh.depth[(size_t)i] < top_depth ? next_top++ : next_deep++;
+    for (int32_t i = 0; i < nn; ++i) {
+        const int32_t d = bvh.depth[(size_t)i];
+        bool front = d < top_depth;
+        if (!front && d == top_depth && extra > 0) {
+            front = true;
+            --extra;
+        }
+        to_new[(size_t)i] = front ? next_top++ : next_deep++;
+    }
     to_new[(size_t)nn] = nn;               // "past the last node" stays the end marker
     out.assign((size_t)nn * 8, 0.0f);
     for (int32_t i = 0; i < nn; ++i) {
