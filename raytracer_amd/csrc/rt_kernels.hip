@@ -916,9 +916,9 @@ struct DeviceGuard {
 
 }  // namespace
 
-// Linked form of the reference-order node array (DevScene::linked): the nodes
-// of the first levels (as many whole levels as fit max_top nodes, then the first
-// nodes of the next level until max_top is reached) are moved to the front, the others keep their preorder behind them, and the implicit
+// Linked form of the reference-order node array (DevScene::linked): the max_top
+// nodes with the largest boxes (the root first) are moved to the front, the
+// others keep their preorder behind them, and the implicit
 // "next node = this one + 1" of the preorder array becomes an explicit link.
 // Returns false when a leaf does not fit the packed encoding (more than 127
 // triangles, or a first triangle beyond 2^24): such trees use the plain array.
@@ -926,30 +926,29 @@ static bool link_nodes(const Bvh &bvh, const std::vector<float> &nodes, int32_t 
                        std::vector<float> &out, int32_t &n_top) {
     const int32_t nn = bvh.n_nodes;
     if (nn <= 0 || (int64_t)nn >= (1 << 30)) return false;
-    std::vector<int32_t> per_depth;
+    // the max_top nodes with the largest boxes: the chance that a ray reaches a node
+    // grows with its box's area, and a parent's box is never smaller than its
+    // child's, so these are the most fetched nodes and form a top of the tree
+    std::vector<float> area((size_t)nn);
     for (int32_t i = 0; i < nn; ++i) {
-        const int32_t d = bvh.depth[(size_t)i];
-        if (d < 0) return false;
-        if ((size_t)d >= per_depth.size()) per_depth.resize((size_t)d + 1, 0);
-        per_depth[(size_t)d]++;
+        const float *q = &nodes[(size_t)i * 8];
+        const float d0 = q[4] - q[0], d1 = q[5] - q[1], d2 = q[6] - q[2];
+        const float a = d0 * d1 + d0 * d2 + d1 * d2;
+        // empty leaves (NaN or inverted boxes) last
+        area[(size_t)i] = (d0 >= 0 && d1 >= 0 && d2 >= 0 && std::isfinite(a)) ? a : -1.0f;
     }
-    int32_t top_depth = 0, count = 0;      // nodes with depth < top_depth go to the front
-    while ((size_t)top_depth < per_depth.size() && count + per_depth[(size_t)top_depth] <= max_top)
-        count += per_depth[(size_t)top_depth++];
-    // the room left after the whole levels goes to the first nodes, in preorder, of the next one
-    int32_t extra = (size_t)top_depth < per_depth.size() ? max_top - count : 0;
-    n_top = count + extra;
+    area[0] = std::numeric_limits<float>::infinity();   // the kernel knows the root as node 0
+    n_top = nn < max_top ? nn : max_top;
+    std::vector<int32_t> by_area((size_t)nn);
+    for (int32_t i = 0; i < nn; ++i) by_area[(size_t)i] = i;
+    std::partial_sort(by_area.begin(), by_area.begin() + n_top, by_area.end(), [&](int32_t x, int32_t y) {
+        return area[(size_t)x] != area[(size_t)y] ? area[(size_t)x] > area[(size_t)y] : x < y;
+    });
+    std::vector<uint8_t> front((size_t)nn, 0);
+    for (int32_t k = 0; k < n_top; ++k) front[(size_t)by_area[(size_t)k]] = 1;
     std::vector<int32_t> to_new((size_t)nn + 1);
     int32_t next_top = 0, next_deep = n_top;
-    for (int32_t i = 0; i < nn; ++i) {
-        const int32_t d = bvh.depth[(size_t)i];
-        bool front = d < top_depth;
-        if (!front && d == top_depth && extra > 0) {
-            front = true;
-            --extra;
-        }
-        to_new[(size_t)i] = front ? next_top++ : next_deep++;
-    }
+    for (int32_t i = 0; i < nn; ++i) to_new[(size_t)i] = front[(size_t)i] ? next_top++ : next_deep++;
     to_new[(size_t)nn] = nn;               // "past the last node" stays the end marker
     out.assign((size_t)nn * 8, 0.0f);
     for (int32_t i = 0; i < nn; ++i) {
