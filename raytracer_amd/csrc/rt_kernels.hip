@@ -1211,7 +1211,7 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const uint32_t n32 = (uint32_t)n_host;
     // wave scheduling thresholds (refill, descend_min, leaf_min): measured optimum per kernel
     const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_wide;
-    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 60 : 48);
+    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : 60;
     const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 32 : 24);
     const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 16 : 8);
     switch (mode) {
