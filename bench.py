@@ -76,11 +76,12 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=0,
                     help="tiles taken per pull with --dynamic (0 = enough for about 32 M camera samples per call)")
     ap.add_argument("--tune", default="", help="stack_entries,refill_below,blocks_per_cu (experiments)")
-    ap.add_argument("--max-paths", type=int, default=1 << 28,
+    ap.add_argument("--max-paths", type=int, default=1 << 29,
                     help="camera samples traced together (0 = the library's default of 64 M = 24 GB of path "
-                         "workspace; the bench takes 256 M = 96 GB of the GPU's 288 GB: every traversal launch "
-                         "ends with a drain phase, and a 64-spp 4K frame in 2 batches instead of 8 is 2.6 %% faster; "
-                         "a batch that does not fit free memory is halved by the library)")
+                         "workspace; the bench takes 512 M = 192 GB of the GPU's 288 GB, so that a 64-spp 4K "
+                         "frame is ONE batch: every traversal launch ends with a drain phase, and one batch "
+                         "instead of eight is 3.5 %% faster; a batch that does not fit free memory is halved "
+                         "by the library)")
     ap.add_argument("--pretend-world", type=int, default=0,
                     help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
                          "no collectives (estimates the per-rank time of a larger job)")

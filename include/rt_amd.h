@@ -189,8 +189,8 @@ rt_status rt_png_decode(const uint8_t *data, size_t size, uint8_t *rgba, size_t 
 rt_status rt_scene_set_texture(rt_scene *scene, int32_t texture_id, const uint8_t *rgba,
                                int32_t width, int32_t height);
 /* Upper bound on camera samples traced together by the tile renderer (sets
- * the size of its device workspace, about 370 bytes per sample at 4 bounces
- * and 1 light sample); default 67108864. */
+ * the size of its device workspace, rt_workspace_bytes_per_path() per sample:
+ * 360 bytes at 4 bounces and 1 light sample); 64 .. 2^29, default 67108864. */
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths);
 /* Upper bound in bytes on the device memory the tile renderer's workspace may
  * take on this scene (0 = none, the default).  A batch whose workspace would

@@ -212,8 +212,8 @@ rt_status rt_scene_set_tuning(rt_scene *scene, int32_t stack_entries, int32_t re
 
 rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
-    if (max_paths < 64 || max_paths > ((uint64_t)1 << 28))
-        return fail(RT_ERR_INVALID, "max_paths must be within [64, 2^28]");
+    if (max_paths < 64 || max_paths > ((uint64_t)1 << 29))
+        return fail(RT_ERR_INVALID, "max_paths must be within [64, 2^29]");
     scene->impl->max_paths_in_flight = (size_t)max_paths;
     return RT_OK;
 }
