@@ -86,7 +86,9 @@ def main():
             "valu_busy": round(c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] * 128), 4),
             "normalisation": "lane_inst_per_ray = SQ_THREAD_CYCLES_VALU / rays; valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / "
                              "(GRBM_GUI_ACTIVE summed over 8 XCDs x 128 SIMDs per XCD); peak issue = 256 CUs x 4 SIMDs x 16 "
-                             "lanes per clock x 2.4 GHz = 39.3 T lane-instructions/s"})
+                             "lanes per clock x 2.4 GHz = 39.3 T lane-instructions/s; valu_busy is an indicator only "
+                             "(roofline.frac does not use it): a value above 1, as the reference-order kernel shows, "
+                             "means that not every counted instruction occupies its SIMD for four cycles"})
     elif what == "traffic":
         fd, wd, log, workload, mode = sys.argv[2:7]
         f, n = sums(fd, mode)
