@@ -13,14 +13,24 @@ HBM, the RGBA8 tiles are gathered to rank 0 over RCCL and the ray counters are
 all-reduced.  The frame is fixed, so scaling is strong.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      achieved algorithmic bytes/s of the traversal kernel against
-                the HBM peak (bytes per ray from traversal counters measured on
-                a sample tile before the timed region)
+  roofline      the traversal kernel against the ceiling that bounds it: VALU
+                lane-instruction issue while the scene is cache resident,
+                measured fabric bytes against the HBM peak beyond that; launch
+                times are measured live with HIP events on the launch stream,
+                per-ray instruction and byte figures come from counter passes
+                kept under profiles/ (the line says which, and whether the
+                kernel sources have changed since)
   cpu_baseline  the CPU oracle (a scalar restatement of the reference
                 algorithm) timed on rank 0's host cores over a bounded sample
                 of the same frame (N=1 only)
+  extra         two more legs timed after the headline region (N=1, default
+                workload and mode only): the same frame in the bit-exact
+                reference-order mode at 16 spp, and the 10M-triangle 8K
+                configuration at 16 spp in the ordered mode
+  ranks         (N>1) per-rank render and gather times and tile counts
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,6 +46,11 @@ HBM_PEAK_GBPS = 8000.0
 # VALU lane-instruction issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz
 VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
 INFINITY_CACHE_MB = 256.0
+# files whose content decides what the traversal kernels do per ray: the counter
+# passes under profiles/ carry the hash of these, and the line says when they changed
+KERNEL_SOURCES = ["raytracer_amd/csrc/rt_kernels.hip", "raytracer_amd/csrc/rt_core.h",
+                  "raytracer_amd/csrc/flatten.cpp", "raytracer_amd/build.py"]
+PROFILE_ROUNDS = ["r03", "r02"]            # newest first
 
 WORKLOADS = {
     # name: grid, triangles, width, height, tiles per dim, leaf, depth, intensity
@@ -52,6 +67,7 @@ WORKLOADS = {
                   bounces=4, light_samples=1, intensity=6.0,
                   label="20k-triangle room mesh, 640x360 (functional check only)"),
 }
+KERNEL_OF = {"fast": "k_trace_fast", "strict": "k_trace_ref<float>", "fp64": "k_trace_ref<double>"}
 
 
 def parse_args():
@@ -68,6 +84,10 @@ def parse_args():
                     help="budget of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the two extra legs (bit-exact mode on the same frame, 10M-triangle 8K frame)")
+    ap.add_argument("--extra", default="strict_cfg3,fast_cfg4",
+                    help="which extra legs a default run adds (comma separated)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (tiles staged through host memory, all ranks may "
                          "share one GPU) is for rehearsing the multi-rank path on a 1-GPU box")
@@ -81,7 +101,7 @@ def parse_args():
                          "workspace; the bench takes 512 M = 192 GB of the GPU's 288 GB, so that a 64-spp 4K "
                          "frame is ONE batch: every traversal launch ends with a drain phase, and one batch "
                          "instead of eight is 3.5 %% faster; a batch that does not fit free memory is halved "
-                         "by the library)")
+                         "by the library, and the line reports the batch actually traced)")
     ap.add_argument("--pretend-world", type=int, default=0,
                     help="experiment on one GPU: render only the tiles rank 0 of this many ranks would own, "
                          "no collectives (estimates the per-rank time of a larger job)")
@@ -94,6 +114,30 @@ def bytes_per_ray(nodes_visited, tris_fetched, rays, node_bytes=56.0):
     in the reference's binary tree (two 24-B boxes + two links) or the whole
     64-B record of the ordered traversal's 4-wide tree."""
     return 32.0 + 16.0 + node_bytes * nodes_visited / rays + 48.0 * tris_fetched / rays
+
+
+def kernel_source_sha():
+    """Hash of the files that decide what the traversal kernels do per ray."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_entry(kind, workload, mode):
+    """(entry, file name) of the newest counter pass under profiles/ for this
+    workload and mode; kind is "valu_per_ray" or "traffic"."""
+    for rnd in PROFILE_ROUNDS:
+        name = f"{rnd}_{kind}.json"
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            entry = json.load(f).get(workload, {}).get(mode)
+        if entry:
+            return entry, name
+    return None, None
 
 
 def cpu_baseline(sc, bvh_export, tables, wl, args, tile_list):
@@ -201,72 +245,100 @@ def launch_ranks(args):
     return subprocess.call(cmd)
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))
-    import torch
-    import torch.distributed as dist
-    from raytracer_amd import api, scenes, tiles
+class Job:
+    """What every leg of one process shares: rank layout, collectives, device."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args, self.torch, self.dist = args, torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
+        if args.backend == "gloo":
+            self.local_rank = self.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo")
+        self.coll_dev = "cuda" if args.backend == "nccl" else "cpu"
+        self.pretend = args.pretend_world if self.world == 1 else 0
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+class Workload:
+    """One synthetic scene resident on this rank's GPU plus the frame's tile list."""
+
+    def __init__(self, job, name):
+        from raytracer_amd import api, scenes
+        self.job, self.name, self.wl = job, name, WORKLOADS[name]
+        wl, dist, rank, world = self.wl, job.dist, job.rank, job.world
+        t0 = time.perf_counter()
+        self.sc = scenes.room_mesh(wl["grid"], seed=wl.get("seed", 0x5EED0002), total=wl["tris"])
+        sc = self.sc
+        self.mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
+        if world == 1:
+            self.bvh = api.Bvh.build(self.mesh, True, wl["leaf"], wl["depth"])
         else:
-            dist.init_process_group("gloo")
-    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
+            # the reference's flow: worker 0 builds the tree, every worker loads it
+            # (main.go:65-90, Renderer.js:235-297); here through the binary cache file
+            import tempfile
+            cache = os.path.join(tempfile.gettempdir(),
+                                 f"rt_bench_{os.environ.get('MASTER_PORT', '0')}_{name}.bvh")
+            self.bvh = None
+            if rank == 0:
+                self.bvh = api.Bvh.build(self.mesh, True, wl["leaf"], wl["depth"])
+                try:
+                    self.bvh.save(cache)
+                except Exception:                      # noqa: BLE001 - the others then build for themselves
+                    pass
+            dist.barrier()
+            if rank != 0:
+                try:
+                    self.bvh = api.Bvh.load(self.mesh, cache)
+                except Exception:                      # noqa: BLE001
+                    self.bvh = api.Bvh.build(self.mesh, True, wl["leaf"], wl["depth"])
+            dist.barrier()
+            if rank == 0 and os.path.exists(cache):
+                os.remove(cache)
+        self.scene = api.Scene(self.mesh, self.bvh, job.local_rank)
+        self.setup_s = time.perf_counter() - t0
+        args = job.args
+        if args.tune:
+            self.scene.set_tuning(*[int(x) for x in args.tune.split(",")])
+        if args.max_paths:
+            self.scene.set_max_paths(args.max_paths)
+        self.tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
+        self.tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
 
-    pretend = args.pretend_world if world == 1 else 0
-    wl = WORKLOADS[args.workload]
-    mode = {"strict": api.MODE_STRICT_F32, "fast": api.MODE_FAST_F32, "fp64": api.MODE_FP64}[args.mode]
+    def release(self):
+        """Frees the scene's device memory (geometry and path workspace)."""
+        self.scene = None
+        import gc
+        gc.collect()
+        self.job.torch.cuda.empty_cache()
 
-    # ---- scene: generated and built on every rank (deterministic), resident per GPU
-    t0 = time.perf_counter()
-    sc = scenes.room_mesh(wl["grid"], seed=wl.get("seed", 0x5EED0002), total=wl["tris"])
-    mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
-    if world == 1:
-        bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
-    else:
-        # the reference's flow: worker 0 builds the tree, every worker loads it
-        # (main.go:65-90, Renderer.js:235-297); here through the binary cache file
-        import tempfile
-        cache = os.path.join(tempfile.gettempdir(),
-                             f"rt_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.bvh")
-        bvh = None
-        if rank == 0:
-            bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
-            try:
-                bvh.save(cache)
-            except Exception:                      # noqa: BLE001 - the others then build for themselves
-                pass
-        dist.barrier()
-        if rank != 0:
-            try:
-                bvh = api.Bvh.load(mesh, cache)
-            except Exception:                      # noqa: BLE001
-                bvh = api.Bvh.build(mesh, True, wl["leaf"], wl["depth"])
-        dist.barrier()
-        if rank == 0 and os.path.exists(cache):
-            os.remove(cache)
-    scene = api.Scene(mesh, bvh, local_rank)
-    setup_s = time.perf_counter() - t0
-    if args.tune:
-        scene.set_tuning(*[int(x) for x in args.tune.split(",")])
-    if args.max_paths:
-        scene.set_max_paths(args.max_paths)
-    tables = (api.default_sample_table(12345, 0xC0FFEE01), api.default_sample_table(100001, 0xC0FFEE02))
 
-    tile_list = scenes.tiles(wl["width"], wl["height"], wl["tiles"])
+def run_leg(job, W, mode_name, spp, steps, warmup):
+    """Times `steps` frames of workload W in one traversal mode and returns the
+    measured figures plus the roofline object of the traversal kernel."""
+    from raytracer_amd import api, scenes, tiles
+    torch, dist, args = job.torch, job.dist, job.args
+    rank, world, pretend, coll_dev, stream = job.rank, job.world, job.pretend, job.coll_dev, job.stream
+    wl, sc, scene, tile_list = W.wl, W.sc, W.scene, W.tile_list
+    mode = {"strict": api.MODE_STRICT_F32, "fast": api.MODE_FAST_F32, "fp64": api.MODE_FP64}[mode_name]
+
     my_tiles = [tile_list[i] for i in tiles.static_assignment(len(tile_list), pretend or world, rank)]
     # every rank's tile images live back to back in one buffer; ranks own equal
     # numbers of pixels only when the tile grid divides evenly, so pad to the maximum
@@ -274,20 +346,19 @@ def main():
     my_px, max_px = px_of[rank], max(px_of)
     if args.dynamic:
         my_px = max_px = sum(t[3] * t[4] for t in tile_list)   # a rank may end up with any tile
-    stream = torch.cuda.current_stream().cuda_stream
     d_accum = torch.empty((max(my_px, 1) * 3,), dtype=torch.float32, device="cuda")
     d_tiles = torch.zeros((max_px * 4,), dtype=torch.uint8, device="cuda")
     frame = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8, device="cuda")
     frame_host = torch.zeros((wl["height"], wl["width"], 4), dtype=torch.uint8) if coll_dev == "cpu" else None
     queue = None
     if args.dynamic and world > 1:
-        chunk = args.chunk or tiles.pull_chunk(len(tile_list), world, tile_list[0][3] * tile_list[0][4] * args.spp)
+        chunk = args.chunk or tiles.pull_chunk(len(tile_list), world, tile_list[0][3] * tile_list[0][4] * spp)
         queue = tiles.TileQueue(dist.distributed_c10d._get_default_store(), len(tile_list), chunk=chunk)
 
-    def make_pass(tile, spp, seed):
+    def make_pass(tile, n_spp, seed):
         tid, x, y, w, h = tile
         return api.pass_from_dict(scenes.make_pass_dict(
-            wl["width"], wl["height"], sc["camera"], spp=spp, bounces=wl["bounces"],
+            wl["width"], wl["height"], sc["camera"], spp=n_spp, bounces=wl["bounces"],
             light_samples=wl["light_samples"], intensity=wl["intensity"], seed=seed,
             x_offset=x, y_offset=y, tile_w=w, tile_h=h, task_id=tid))
 
@@ -301,17 +372,19 @@ def main():
         key = group[0][0], len(group)   # (first tile id, count) names a group: pulls are contiguous id ranges
         arr = pass_cache.get(key)
         if arr is None:
-            arr = pass_cache[key] = api.pass_array([make_pass(t, args.spp, 0) for t in group])
+            arr = pass_cache[key] = api.pass_array([make_pass(t, spp, 0) for t in group])
         for i, t in enumerate(group):
             arr[i].rng_seed = 1 + 1000 * step + t[0]
         return scene.render_tiles_device(arr, d_accum.data_ptr() + off_px * 12, d_tiles.data_ptr() + off_px * 4,
                                          mode=mode, stream=stream, want_stats=True)
 
     def run_step(step, collect):
-        rays, kernel_ms, launches = 0, 0.0, 0
+        rays, kernel_ms, launches, n_pulls, n_tiles = 0, 0.0, 0, 0, 0
+        t_start = time.perf_counter()
         if queue is None:
-            st = render_tiles(my_tiles, step)
-            rays, kernel_ms, launches = st["rays"], st["kernel_ms"], st["kernel_launches"]
+            st = render_tiles(my_tiles, step)       # returns after the ray-count read-back: the tiles are done
+            rays, kernel_ms, launches, n_tiles = st["rays"], st["kernel_ms"], st["kernel_launches"], len(my_tiles)
+            t_rendered = time.perf_counter()
             if not args.no_gather and not pretend:
                 if coll_dev == "cuda":
                     tiles.gather_static(d_tiles, tile_list, world, rank, frame)
@@ -326,6 +399,7 @@ def main():
                 got = queue.pull()
                 if not got:
                     break
+                n_pulls += 1
                 group = [tile_list[i] for i in got]
                 st = render_tiles(group, step, off_px)
                 rays += st["rays"]
@@ -333,15 +407,24 @@ def main():
                 launches += st["kernel_launches"]
                 my_ids += got
                 off_px += sum(t[3] * t[4] for t in group)
+            n_tiles = len(my_ids)
+            t_rendered = time.perf_counter()
             if not args.no_gather:
                 if coll_dev == "cuda":
                     tiles.gather_dynamic(d_tiles, my_ids, tile_list, world, rank, frame)
                 else:
                     tiles.gather_dynamic(d_tiles.cpu(), my_ids, tile_list, world, rank, frame_host)
-        if collect:
+        if world > 1:
+            torch.cuda.synchronize()                # the exchange is asynchronous on the stream: time it here
+        t_end = time.perf_counter()
+        if collect is not None:
             collect["rays"] += rays
             collect["kernel_ms"] += kernel_ms
             collect["launches"] += launches
+            collect["render_s"] += t_rendered - t_start
+            collect["gather_s"] += t_end - t_rendered
+            collect["pulls"] += n_pulls
+            collect["tiles"] += n_tiles
         return rays
 
     # ---- bytes/ray of this workload from the counting kernel on a sample tile (untimed)
@@ -361,22 +444,18 @@ def main():
     nodes_per_ray = st["nodes_visited"] / max(st["rays"], 1)
     tris_per_ray = st["tris_fetched"] / max(st["rays"], 1)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for w_ in range(args.warmup):
+    for w_ in range(warmup):
         run_step(-1 - w_, None)
-    acc = {"rays": 0, "kernel_ms": 0.0, "launches": 0}
-    barrier()
+    acc = {"rays": 0, "kernel_ms": 0.0, "launches": 0, "render_s": 0.0, "gather_s": 0.0, "pulls": 0, "tiles": 0}
+    job.barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(steps):
         run_step(s, acc)
-    barrier()
+    job.barrier()
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([float(acc["rays"]), elapsed, acc["kernel_ms"]], dtype=torch.float64, device=coll_dev)
+    per_rank = None
     if world > 1:
         t_max = tot.clone()
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -384,107 +463,207 @@ def main():
         elapsed = float(t_max[1])
         kernel_ms = float(t_max[2])
         total_rays = float(tot[0])
+        # what each rank spent where, so that a shortfall at N ranks can be attributed
+        mine = torch.tensor([acc["render_s"] * 1e3 / steps, acc["gather_s"] * 1e3 / steps, acc["kernel_ms"] / steps,
+                             acc["tiles"] / steps, acc["pulls"] / steps, acc["rays"] / steps],
+                            dtype=torch.float64, device=coll_dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        cols = list(zip(*[e.tolist() for e in every]))
+        per_rank = {"render_ms_per_step": [round(v, 3) for v in cols[0]],
+                    "gather_ms_per_step": [round(v, 3) for v in cols[1]],
+                    "traversal_ms_per_step": [round(v, 3) for v in cols[2]],
+                    "tiles_per_step": [round(v, 2) for v in cols[3]],
+                    "pulls_per_step": [round(v, 2) for v in cols[4]],
+                    "rays_per_step": [round(v, 1) for v in cols[5]],
+                    "render_ms_min_max": [round(min(cols[0]), 3), round(max(cols[0]), 3)],
+                    "gather_ms_min_max": [round(min(cols[1]), 3), round(max(cols[1]), 3)],
+                    "note": "render = host clock around this rank's render calls (they return after the ray-count "
+                            "read-back); gather = the exchange step up to a device synchronise, which on every rank "
+                            "but the slowest includes waiting for the slowest"}
     else:
         total_rays, kernel_ms = float(acc["rays"]), acc["kernel_ms"]
 
+    if rank != 0:
+        return None
+    info = scene.info()
+    # what the library holds in HBM for the scene: triangle records, both tree views, shading words, tables
+    scene_mb = info["total_device_bytes"] / 1e6
+    value = total_rays / elapsed / 1e6
+    # roofline of the traversal kernel, measured on this rank: rays over the time its
+    # traversal launches took (HIP events on the launch stream, inside the timed region)
+    rank_rays = float(acc["rays"])
+    trav_s = acc["kernel_ms"] * 1e-3
+    rays_per_s = rank_rays / trav_s if trav_s > 0 else 0.0
+    algorithmic = rays_per_s * bpr / 1e9                       # GB/s of counted record + triangle fetches
+
+    # fabric bytes per ray and VALU lane-instructions per ray are counter measurements of this
+    # kernel on this workload, taken in separate rocprofv3 --pmc runs and kept under profiles/
+    fabric, fabric_file = profile_entry("traffic", W.name, mode_name)
+    valu, valu_file = profile_entry("valu_per_ray", W.name, mode_name)
+    sha_now = kernel_source_sha()
+    head = {}
+    for label, entry, fname in (("valu", valu, valu_file), ("traffic", fabric, fabric_file)):
+        if entry:
+            head[label] = {"file": f"profiles/{fname}", "git_head": entry.get("git_head"),
+                           "rt_version": entry.get("rt_version"), "kernel_source_sha": entry.get("kernel_source_sha"),
+                           "matches_this_source": entry.get("kernel_source_sha") == sha_now}
+    stale = [k for k, v in head.items() if not v["matches_this_source"]]
+    traffic = traffic_src = None
+    if fabric and acc["launches"]:
+        traffic = round(fabric["hbm_bytes_per_ray"] * rank_rays / acc["launches"], 1)
+        traffic_src = (f"profiles/{fabric_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per ray) "
+                       "x this run's rays per launch")
+    hbm_rate = fabric["hbm_bytes_per_ray"] * rays_per_s / 1e9 if fabric else None
+    resident = scene_mb < INFINITY_CACHE_MB
+    roof = {"kernel": KERNEL_OF[mode_name], "traffic": traffic, "traffic_source": traffic_src,
+            "rays_per_s_in_kernel": round(rays_per_s, 1),
+            "bytes_per_ray": round(bpr, 1), "bytes_per_ray_reference_order": round(bpr_ref, 1),
+            "algorithmic_GBps": round(algorithmic, 1),
+            "algorithmic_GBps_reference_order": round(algorithmic * bpr_ref / bpr, 1) if bpr > 0 else 0.0,
+            "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+            "kernel_ms_per_step": round(kernel_ms / steps, 3),
+            "kernel_launches_per_step": acc["launches"] // max(steps, 1),
+            "kernel_avg_launch_ms": round(acc["kernel_ms"] / max(acc["launches"], 1), 4),
+            "scene_mb": round(scene_mb, 1),
+            "profile_head": {"kernel_source_sha_now": sha_now, "rt_version_now": api.version(), **head},
+            "profile_warning": (f"the kernel sources changed after the counter pass of: {', '.join(stale)} -- "
+                                "per-ray constants below are the older kernel's") if stale else None}
+    if resident:
+        # the scene lives in L2 / Infinity Cache: HBM is not the ceiling.  The kernel is bound by
+        # VALU issue (profiles/): achieved = active lane-instructions per ray (SQ_THREAD_CYCLES_VALU
+        # / rays) x rays/s against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+        lane_per_ray = valu["lane_inst_per_ray"] if valu else None
+        ach = lane_per_ray * rays_per_s / 1e12 if lane_per_ray else None
+        roof.update({"bound": "valu", "unit": "Tlane-inst/s", "peak": round(VALU_PEAK_TLANE, 2),
+                     "achieved": round(ach, 3) if ach else None,
+                     "frac": round(ach / VALU_PEAK_TLANE, 4) if ach else None,
+                     "lane_inst_per_ray": lane_per_ray,
+                     "wave_inst_per_ray": valu.get("wave_inst_per_ray") if valu else None,
+                     "avg_active_lanes": valu.get("avg_active_lanes") if valu else None,
+                     "lane_inst_source": f"profiles/{valu_file} (tools/pmc_to_profiles.py valu)" if valu else None})
+        roof["hbm"] = {"achieved": round(hbm_rate, 1) if hbm_rate else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None,
+                       "note": "measured fabric bytes, not algorithmic ones"}
+    else:
+        # beyond the Infinity Cache: HBM, priced at the MEASURED fabric bytes
+        roof.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                     "achieved": round(hbm_rate, 1) if hbm_rate else None,
+                     "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None})
+    # the batch the library actually traced: the bound it holds now (lowered for good when a
+    # batch did not fit device memory), capped by the camera samples one call had
+    asked = int(args.max_paths) if args.max_paths else 1 << 26
+    samples_per_call = max(sum(t[3] * t[4] for t in my_tiles), 1) * spp
+    effective = min(int(info["max_paths_in_flight"]), samples_per_call)
+    return {"value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "spp": spp, "mode": mode_name, "rays_per_step": total_rays / steps, "total_rays": total_rays,
+            "queue": queue is not None, "resident": resident,
+            "paths_per_batch": effective, "paths_per_batch_asked": asked,
+            "batch_halved_by_library": int(info["max_paths_in_flight"]) < asked,
+            "workspace_gb": round(info["workspace_bytes"] / 1e9, 2),
+            "roofline": roof, "per_rank": per_rank,
+            "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray, "rays_per_s_in_kernel": rays_per_s}
+
+
+def gather_ceiling(job, W, leg):
+    """Beside the VALU roofline of a cache-resident scene: the gather rate of the
+    cache hierarchy for tables of this scene's size (rt_gather_probe, untimed)."""
+    from raytracer_amd import api
+    info = W.scene.info()
+    recs = {}
+    for label, nbytes in (("ordered_view", info["ordered_bytes"]),
+                          ("ordered_view_plus_triangles", info["ordered_bytes"] + info["tri_bytes"])):
+        if nbytes:
+            recs[label] = {"table_mb": round(nbytes / 1e6, 1),
+                           "records_per_s": round(api.gather_probe(job.local_rank, nbytes), 1)}
+    kernel_recs = (leg["nodes_per_ray"] + 0.75 * leg["tris_per_ray"]) * leg["rays_per_s_in_kernel"]   # a triangle record is 48 of 64 bytes
+    uniform = recs.get("ordered_view_plus_triangles", {}).get("records_per_s")
+    return {"uniform_gather": recs, "kernel_records_per_s": round(kernel_recs, 1),
+            "kernel_over_uniform_gather": round(kernel_recs / uniform, 3) if uniform else None,
+            "note": "rt_gather_probe: every lane chases UNIFORMLY random 64-byte records through a table "
+                    "of the given size (measured by this run outside its timed region). The traversal's "
+                    "fetches are not uniform -- the top of the tree is re-read by every ray and stays in "
+                    "L1/L2 -- so its record rate can exceed the uniform figure; the ratio says how much "
+                    "of its fetch stream the nearer cache levels absorb, it is not a fraction of a ceiling"}
+
+
+def extra_object(W, leg):
+    """One extra leg as it appears under "extra" in the line."""
+    r = leg["roofline"]
+    return {"workload": f"{W.name}: {W.wl['label']}, {leg['spp']} spp", "traversal_mode": leg["mode"],
+            "value": leg["value"], "unit": "Mrays/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+            "warmup": leg["warmup"], "rays_per_step": leg["rays_per_step"],
+            "triangles": int(W.mesh.n_tris), "width": W.wl["width"], "height": W.wl["height"], "spp": leg["spp"],
+            "paths_per_batch": leg["paths_per_batch"], "batch_halved_by_library": leg["batch_halved_by_library"],
+            "workspace_gb": leg["workspace_gb"], "setup_s": round(W.setup_s, 2),
+            "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                               "rays_per_s_in_kernel", "kernel_ms_per_step",
+                                               "kernel_launches_per_step", "kernel_avg_launch_ms", "nodes_per_ray",
+                                               "tris_per_ray", "bytes_per_ray", "scene_mb", "lane_inst_per_ray",
+                                               "profile_head", "profile_warning")}}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    job = Job(args)
+    world, rank = job.world, job.rank
+
+    W = Workload(job, args.workload)
+    leg = run_leg(job, W, args.mode, args.spp, args.steps, args.warmup)
+
+    out = None
     if rank == 0:
-        # what the library holds in HBM for the scene: triangle records, both tree views, shading words, tables
-        scene_mb = scene.info()["total_device_bytes"] / 1e6
-        value = total_rays / elapsed / 1e6
-        # roofline of the traversal kernel, measured on this rank: rays over the time its
-        # traversal launches took (HIP events on the launch stream, inside the timed region)
-        rank_rays = float(acc["rays"])
-        trav_s = acc["kernel_ms"] * 1e-3
-        rays_per_s = rank_rays / trav_s if trav_s > 0 else 0.0
-        algorithmic = rays_per_s * bpr / 1e9                       # GB/s of counted record + triangle fetches
-        kernel = {"fast": "k_trace_fast", "strict": "k_trace_ref<float>", "fp64": "k_trace_ref<double>"}[args.mode]
-
-        def profile_entry(name):
-            path = os.path.join(ROOT, "profiles", name)
-            if not os.path.exists(path):
-                return None
-            with open(path) as f:
-                return json.load(f).get(args.workload, {}).get(args.mode)
-
-        # fabric bytes per ray and VALU lane-instructions per ray are counter measurements of this
-        # kernel on this workload, taken in separate rocprofv3 --pmc runs and kept under profiles/
-        fabric = profile_entry("r02_traffic.json")
-        valu = profile_entry("r02_valu_per_ray.json")
-        traffic = traffic_src = None
-        if fabric and acc["launches"]:
-            traffic = round(fabric["hbm_bytes_per_ray"] * rank_rays / acc["launches"], 1)
-            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per ray) x this run's rays per launch"
-        hbm_rate = fabric["hbm_bytes_per_ray"] * rays_per_s / 1e9 if fabric else None
-        resident = scene_mb < INFINITY_CACHE_MB
-        roof = {"kernel": kernel, "traffic": traffic, "traffic_source": traffic_src,
-                "rays_per_s_in_kernel": round(rays_per_s, 1),
-                "bytes_per_ray": round(bpr, 1), "bytes_per_ray_reference_order": round(bpr_ref, 1),
-                "algorithmic_GBps": round(algorithmic, 1),
-                "algorithmic_GBps_reference_order": round(algorithmic * bpr_ref / bpr, 1) if bpr > 0 else 0.0,
-                "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
-                "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
-                "kernel_launches_per_step": acc["launches"] // max(args.steps, 1),
-                "kernel_avg_launch_ms": round(acc["kernel_ms"] / max(acc["launches"], 1), 4),
-                "scene_mb": round(scene_mb, 1)}
-        if resident:
-            # the scene lives in L2 / Infinity Cache: HBM is not the ceiling.  The kernel is bound by
-            # VALU issue (profiles/): achieved = active lane-instructions per ray (SQ_THREAD_CYCLES_VALU
-            # / rays) x rays/s against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
-            lane_per_ray = valu["lane_inst_per_ray"] if valu else None
-            ach = lane_per_ray * rays_per_s / 1e12 if lane_per_ray else None
-            roof.update({"bound": "valu", "unit": "Tlane-inst/s", "peak": round(VALU_PEAK_TLANE, 2),
-                         "achieved": round(ach, 3) if ach else None,
-                         "frac": round(ach / VALU_PEAK_TLANE, 4) if ach else None,
-                         "lane_inst_per_ray": lane_per_ray,
-                         "lane_inst_source": "profiles/r02_valu_per_ray.json (tools/pmc_valu.py)" if valu else None})
-            # beside it: the gather ceiling of the cache hierarchy for tables of this scene's size
-            info = scene.info()
-            recs = {}
-            for label, nbytes in (("ordered_view", info["ordered_bytes"]),
-                                  ("ordered_view_plus_triangles", info["ordered_bytes"] + info["tri_bytes"])):
-                if nbytes:
-                    recs[label] = {"table_mb": round(nbytes / 1e6, 1),
-                                   "records_per_s": round(api.gather_probe(local_rank, nbytes), 1)}
-            kernel_recs = (nodes_per_ray + 0.75 * tris_per_ray) * rays_per_s     # a triangle record is 48 of 64 bytes
-            uniform = recs.get("ordered_view_plus_triangles", {}).get("records_per_s")
-            roof["l2_mall"] = {"uniform_gather": recs, "kernel_records_per_s": round(kernel_recs, 1),
-                               "kernel_over_uniform_gather": round(kernel_recs / uniform, 3) if uniform else None,
-                               "note": "rt_gather_probe: every lane chases UNIFORMLY random 64-byte records through a table "
-                                       "of the given size (measured by this run outside its timed region). The traversal's "
-                                       "fetches are not uniform -- the top of the tree is re-read by every ray and stays in "
-                                       "L1/L2 -- so its record rate can exceed the uniform figure; the ratio says how much "
-                                       "of its fetch stream the nearer cache levels absorb, it is not a fraction of a ceiling"}
-            roof["hbm"] = {"achieved": round(hbm_rate, 1) if hbm_rate else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None,
-                           "note": "measured fabric bytes, not algorithmic ones"}
-        else:
-            # beyond the Infinity Cache: HBM, priced at the MEASURED fabric bytes
-            roof.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                         "achieved": round(hbm_rate, 1) if hbm_rate else None,
-                         "frac": round(hbm_rate / HBM_PEAK_GBPS, 4) if hbm_rate else None})
+        wl, roof = W.wl, leg["roofline"]
+        if leg["resident"]:
+            roof["l2_mall"] = gather_ceiling(job, W, leg)
         out = {
             "metric": "Mrays/sec (primary+secondary)",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "value": leg["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": leg["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if mode != api.MODE_FP64 else "f64", "data": "synthetic",
+            "dtype": "f32" if args.mode != "fp64" else "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['label']}, {args.spp} spp",
-                       "triangles": int(mesh.n_tris), "bvh_nodes": int(bvh.n_nodes),
+                       "triangles": int(W.mesh.n_tris), "bvh_nodes": int(W.bvh.n_nodes),
                        "width": wl["width"], "height": wl["height"], "spp": args.spp,
                        "bounces": wl["bounces"], "light_samples": wl["light_samples"],
-                       "tiles": len(tile_list),
-                       "tile_assignment": "dynamic pull queue" if queue is not None else "block-cyclic",
+                       "tiles": len(W.tile_list),
+                       "tile_assignment": "dynamic pull queue" if leg["queue"] else "block-cyclic",
                        "traversal_mode": args.mode, "parallelism": f"tiles/{world}gpu",
-                       "paths_per_batch": int(args.max_paths) if args.max_paths else 1 << 26,
-                       "rays_per_step": total_rays / args.steps, "setup_s": round(setup_s, 2)},
+                       "paths_per_batch": leg["paths_per_batch"],
+                       "paths_per_batch_asked": leg["paths_per_batch_asked"],
+                       "batch_halved_by_library": leg["batch_halved_by_library"],
+                       "workspace_gb": leg["workspace_gb"],
+                       "rays_per_step": leg["rays_per_step"], "setup_s": round(W.setup_s, 2)},
             "roofline": roof,
         }
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(sc, bvh.export(), tables, wl, args, tile_list)
+        if leg["per_rank"]:
+            out["ranks"] = leg["per_rank"]
+
+    # ---- extra legs: the bit-exact mode on the same frame, and the 10M-triangle 8K frame
+    want_extra = (world == 1 and not args.no_extra and not job.pretend and args.workload == "cfg3"
+                  and args.mode == "fast" and not args.tune)
+    extra = {}
+    t_extra = time.perf_counter()
+    if want_extra and "strict_cfg3" in args.extra:
+        extra["strict_cfg3"] = extra_object(W, run_leg(job, W, "strict", 16, 2, 1))
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(W.sc, W.bvh.export(), W.tables, W.wl, args, W.tile_list)
+    if want_extra and "fast_cfg4" in args.extra:
+        W.release()                                  # its 192 GB of path workspace make room for the next scene's
+        W = None
+        W4 = Workload(job, "cfg4")
+        extra["fast_cfg4"] = extra_object(W4, run_leg(job, W4, "fast", 16, 1, 1))
+        W4.release()
+    if rank == 0:
+        if extra:
+            extra["seconds"] = round(time.perf_counter() - t_extra, 1)
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        job.dist.barrier()
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -153,6 +153,11 @@ typedef struct rt_scene_info {
      * most 2^24-2 triangles; without it RT_MODE_FAST_F32 runs the reference
      * order) */
     int32_t linked_view, ordered_view;
+    /* the tile renderer's current bound on camera samples traced together (what
+     * rt_scene_set_max_paths set, lowered for good by a render call whose batch
+     * did not fit device memory or the workspace limit), and the bytes of path
+     * workspace the scene holds right now */
+    uint64_t max_paths_in_flight, workspace_bytes;
 } rt_scene_info;
 
 /* context.go:172-226 on the host, no device needed: the area light of a mesh.

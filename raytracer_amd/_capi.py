@@ -35,7 +35,8 @@ class SceneInfo(C.Structure):
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64),
                 ("total_device_bytes", C.c_uint64), ("ordered_bytes", C.c_uint64),
                 ("linked_view", C.c_int32),
-                ("ordered_view", C.c_int32)]
+                ("ordered_view", C.c_int32),
+                ("max_paths_in_flight", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
 
 class Stats(C.Structure):

@@ -214,6 +214,8 @@ rt_status rt_scene_set_max_paths(rt_scene *scene, uint64_t max_paths) {
     if (!scene || !scene->impl) return fail(RT_ERR_INVALID, "scene is NULL");
     if (max_paths < 64 || max_paths > ((uint64_t)1 << 29))
         return fail(RT_ERR_INVALID, "max_paths must be within [64, 2^29]");
+    // render calls read the bound, and lower it when a batch does not fit, under this lock
+    std::lock_guard<std::mutex> lock(scene->impl->render_mu);
     scene->impl->max_paths_in_flight = (size_t)max_paths;
     return RT_OK;
 }
@@ -245,8 +247,13 @@ rt_status rt_scene_create(const rt_mesh *mesh, const rt_bvh *bvh, int32_t device
 
 rt_status rt_scene_info_get(const rt_scene *scene, rt_scene_info *out) {
     if (!scene || !scene->impl || !out) return fail(RT_ERR_INVALID, "NULL argument");
-    const rt::Scene &s = *scene->impl;
+    rt::Scene &s = *scene->impl;
     std::memset(out, 0, sizeof *out);
+    {
+        std::lock_guard<std::mutex> lock(s.render_mu);
+        out->max_paths_in_flight = s.max_paths_in_flight;
+        out->workspace_bytes = s.ws_block_bytes;
+    }
     out->n_tris = s.n_tris;
     out->n_nodes = s.n_nodes;
     out->max_depth = s.max_depth;

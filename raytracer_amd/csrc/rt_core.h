@@ -101,6 +101,19 @@ constexpr int32_t kFastMaxLeaf = 4;     // ordered view: larger leaf ranges are 
 constexpr int32_t kWideFloats = 16;     // one ordered-traversal record: frame + 4 quantised child boxes + 4 refs = 64 bytes
 constexpr int32_t kFastStackEntries = 96;   // per-ray stack of the ordered traversal
 constexpr int32_t kFastMaxTris = (1 << 24) - 2;
+// Ordered traversal: a child box or stack entry is still entered when its entry
+// distance lies up to this factor beyond the current hit distance.  Two
+// triangles that share an edge can be hit at bit-equal distances, and the tie
+// goes to the earlier array position (the one the reference's left-first order
+// meets first, bvh.go:125), so the box of that earlier triangle has to be
+// entered although a hit AT its distance is already known.  The box's entry
+// distance and the triangle's hit distance come out of different float32
+// computations and can disagree by a few rounding steps; 2^-18 (32 steps)
+// covers that with a wide margin and admits no measurable number of extra
+// boxes.  Triangles in an admitted box are still accepted only below the hit
+// distance, or at it from an earlier position.  FLT_MAX times the factor is
+// +inf, which admits every finite entry distance, as FLT_MAX itself does.
+constexpr float kTieSlack = 1.0f + 0x1p-18f;
 
 // ---------------------------------------------------------------------------
 // Ray state for the reference-order traversal.
@@ -251,8 +264,9 @@ RT_HD void traverse_ref_order(const DevScene &s, const Ray<Real> &r, Hit<Real> &
 
 // The fast mode's ordered traversal, lane-serial form: nearer child first, the
 // farther one stacked with its entry distance and dropped at pop time once a
-// closer hit exists (an entry AT the hit distance is kept: it may hold a
-// triangle that ties with the hit and sits earlier in the array).  Box slabs use the reference's (bound - origin) * invDir;
+// closer hit exists (an entry at the hit distance, or within kTieSlack of it, is
+// kept: it may hold a triangle that ties with the hit and sits earlier in the
+// array).  Box slabs use the reference's (bound - origin) * invDir;
 // the triangle test is tri_test() unchanged, so t, u, v of a given triangle are
 // bit-identical to the reference order's.
 // Sorts four (entry distance, child ref) pairs by distance, ascending, with a
@@ -310,7 +324,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);
                 ref[k] = (uint32_t)f2i(q[12 + k]);
                 // an unused slot has an inverted box (tn > tf) and needs no test of its own
-                const bool hit = tn <= tf && tn <= h.t && tf > 0;
+                const bool hit = (tn <= fminf(tf, h.t * kTieSlack)) & (tf > 0);
                 key[k] = hit ? tn : kF32Inf;
                 n_hit += hit ? 1 : 0;
             }
@@ -319,7 +333,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 cur = kRefDone;
                 while (sp > 0) {
                     sp--;
-                    if (stack_t[sp] <= h.t) { cur = stack_ref[sp]; break; }
+                    if (stack_t[sp] <= h.t * kTieSlack) { cur = stack_ref[sp]; break; }
                 }
             } else {
                 // farthest first, so that the nearest of the rest is popped first
@@ -343,7 +357,7 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
         cur = kRefDone;
         while (sp > 0) {
             sp--;
-            if (stack_t[sp] <= h.t) { cur = stack_ref[sp]; break; }
+            if (stack_t[sp] <= h.t * kTieSlack) { cur = stack_ref[sp]; break; }
         }
         if (cur == kRefDone) return;
     }

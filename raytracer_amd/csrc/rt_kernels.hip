@@ -315,11 +315,11 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // entries live in LDS ([entry][lane], 8 bytes each: child reference + entry
 // distance), deeper entries spill to scratch.  A popped entry whose entry
 // distance lies beyond the current hit distance is dropped without touching
-// memory; one AT the hit distance is kept, like a child box entered exactly at
-// it, because a triangle in it may tie with the current hit and sit earlier in
-// the array, and exact ties go to the earlier position (the triangle the
-// reference's left-first order meets first).  Triangle arithmetic is the
-// reference's.
+// memory; one at the hit distance or within kTieSlack of it is kept, like a
+// child box entered there, because a triangle in it may tie with the current
+// hit and sit earlier in the array, and exact ties go to the earlier position
+// (the triangle the reference's left-first order meets first).  Triangle
+// arithmetic is the reference's.
 //
 // The loop alternates two phases, "descend through interior records until this
 // lane holds a leaf" and "test the leaf's triangles", so that the lanes of a
@@ -374,6 +374,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     // (origin x, origin y), (origin z, 1/dir x), (1/dir y, 1/dir z)
     f2 r_oxy{0, 0}, r_ozix{0, 0}, r_iyz{0, 0};
     float h_t = 0;               // closest hit so far
+    float h_lim = 0;             // h_t * kTieSlack: entry distances up to here are still entered
     int32_t h_pos = -1;
     // The lane's whole state is where it stands, in the form of a child reference:
     // an interior record index (>= 0 as a signed number), or leaf bit | triangles
@@ -404,7 +405,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
             asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
             if (sp >= kStackLds) e = spill[sp - kStackLds];
-            if (i2f((int32_t)e.y) <= h_t) {
+            if (i2f((int32_t)e.y) <= h_lim) {
                 stand_on(e.x);
                 return;
             }
@@ -433,6 +434,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 r_oxy.x = a.x; r_oxy.y = a.y; r_ozix.x = a.z;
                 r_ozix.y = 1.0f / b.x; r_iyz.x = 1.0f / b.y; r_iyz.y = 1.0f / b.z;   // ray.go:33-37
                 h_t = a.w;
+                h_lim = a.w * kTieSlack;
                 h_pos = -1;
                 my_park[0 * 256] = 0.0f;
                 my_park[1 * 256] = 0.0f;
@@ -459,7 +461,10 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (m_desc == 0) break;
             if ((int)__popcll(m_desc) < descend_min && wave_ballot((int32_t)where < -2) != 0) break;
             if (descending) {
-            const f4 *q = s.wide + 4 * (size_t)where;
+            // byte offset in 32 bits (the record table stays below 4 GB: at most one record
+            // per triangle, 2^24 of them), so that the loads take the table's base from
+            // scalar registers and no 64-bit address is built per lane
+            const f4 *q = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.wide) + (where << 6));
             const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (COUNT) { c_nodes++; c_box += 4; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // frame of the record, then per child: decode the six planes with one
@@ -494,7 +499,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);        \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                const bool hit = tn <= tf && tn <= h_t && tf > 0;   /* unused slot: inverted box */ \
+                /* tn <= tf && tn <= h_lim && tf > 0 with one compare less (unused slot: inverted box) */ \
+                const bool hit = (tn <= fminf(tf, h_lim)) & (tf > 0);                       \
                 key[k] = hit ? tn : kF32Inf;                                                \
             }
             RT_SLAB(0)
@@ -530,15 +536,17 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             if (in_leaf) {
             const int32_t tri_i = (int32_t)(where & 0xFFFFFFu), tri_n = (int32_t)((where >> 24) & 0x7Fu);
             const bool two = tri_n > 1;
-            const f4 *qa = s.tris + 3 * (size_t)tri_i;
-            const f4 *qb = qa + (two ? 3 : 0);
+            // 32-bit byte offsets (at most 2^24 triangles of 48 bytes), see the descent step
+            const uint32_t off_a = (uint32_t)tri_i * 48u;
+            uint32_t off_b = off_a + (two ? 48u : 0u);
+            asm volatile("" : "+v"(off_b));   // stays one 32-bit offset beside the scalar base
+            const f4 *qa = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_a);
+            const f4 *qb = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_b);
             f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
             const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
             // all six loads are issued here, together: left alone the compiler moves
             // the first triangle's into the branch that tests it and splits them up
-            asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w));
-            asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w));
-            asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w));
+            asm volatile("" :: "v"(a0.x), "v"(a1.x), "v"(a2.x));
             if (COUNT) { c_fetch += two ? 2 : (tri_n > 0 ? 1 : 0); c_lb++; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wb++; }
             // the full ray only exists here
             Ray<float> r;
@@ -561,6 +569,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool take_b = two & in_b & ((tb < h_t) | ((tb == h_t) & (tri_i + 1 < h_pos)));
             h_t = take_b ? tb : h_t;
             h_pos = take_b ? tri_i + 1 : h_pos;
+            h_lim = h_t * kTieSlack;
             if (take_a | take_b) {
                 my_park[0 * 256] = take_b ? ub : ua;
                 my_park[1 * 256] = take_b ? vb : va;
@@ -865,7 +874,7 @@ struct FixedWorkspace {
     size_t bytes = 0;
     hipEvent_t done = nullptr;    // recorded at the end of every call that used it
     std::mutex mu;                // calls take turns on the host
-    bool ready = false;
+    std::atomic<bool> ready{false};   // set once under g_static_mu, read by every static call
 };
 
 // Per-device state of the static workspace (the `scratch` array at the top of
@@ -1523,6 +1532,13 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
         if (l.total > fixed->bytes) return fail(RT_ERR_INVALID, "batch does not fit the given workspace block");
         w = ws_carve(fixed->ptr, l);
     } else {
+        // A call that is being captured into a graph must not allocate or free: that
+        // would invalidate the capture, and freeing could take the workspace from
+        // under a call still running on another stream.
+        if (capturing && (sc.ws_paths < n_pix * n_samp || sc.ws_L < L || sc.ws_B < B ||
+                          (!tiles.empty() && sc.tile_cap < tiles.size())))
+            return fail(RT_ERR_STATE, "the path workspace would have to grow during stream capture: render once "
+                                      "with these settings before capturing, or use rt_render_tile_static");
         // the workspace is sized by the batch; when it does not fit (free device
         // memory, or the scene's workspace limit), halve the batch (down to 64 k
         // samples) and remember the smaller bound

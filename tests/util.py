@@ -111,22 +111,23 @@ def classify_fast_differences(O, verts, order, rays, fast, ref_tri, ref_t, degen
                    t, u, v: the reference's box test pruned it (its box test
                    is done in float32 on the exact boxes, the ordered mode's on
                    boxes that contain them)
-      equal_t_earlier / equal_t_later
-                   the same with t == t_ref bit for bit: two triangles share the
-                   hit point (an edge of the mesh).  Both traversals keep the
-                   first they meet unless the other sits earlier in the array AND
-                   its box is still entered at or before t; either one's float32
-                   box test may put that entry distance one rounding step beyond
-                   t, so the tie can fall either way.  The hit distance is the
-                   same, the ordered mode never reports a farther hit.
+      equal_t_earlier
+                   the same with t == t_ref bit for bit, at an EARLIER array
+                   position than the reference order's triangle: two triangles
+                   share the hit point (an edge of the mesh) and the reference's
+                   strict box test (boxTmin < *tmin, bvh.go:133-141) pruned the
+                   box of the earlier one.  The opposite case -- the ordered mode
+                   keeping the later triangle of such a tie -- is NOT permitted:
+                   the ordered mode enters every box whose entry distance lies
+                   within a few rounding steps of the hit distance, so it always
+                   finds the earlier triangle.
     and, only with degenerate_ok (rays with a zero or denormal direction
     component, whose infinite inverse direction makes NaN slabs that the two
     slab forms treat differently):
       nan_slab     any other outcome on such a ray
     Returns the class counts."""
     verts = np.asarray(verts, np.float32).reshape(-1, 3, 3)
-    counts = {"rays": int(len(rays)), "differing": 0, "closer_hit": 0, "equal_t_earlier": 0, "equal_t_later": 0,
-              "nan_slab": 0}
+    counts = {"rays": int(len(rays)), "differing": 0, "closer_hit": 0, "equal_t_earlier": 0, "nan_slab": 0}
     differ = np.nonzero(fast["tri_pos"] != ref_tri)[0]
     counts["differing"] = int(len(differ))
     for i in differ:
@@ -150,8 +151,8 @@ def classify_fast_differences(O, verts, order, rays, fast, ref_tri, ref_t, degen
                 if t32 < ref_t[i]:
                     counts["closer_hit"] += 1
                     ok = True
-                elif t32 == ref_t[i] and pr >= 0:
-                    counts["equal_t_earlier" if pf < pr else "equal_t_later"] += 1
+                elif t32 == ref_t[i] and 0 <= pf < pr:
+                    counts["equal_t_earlier"] += 1
                     ok = True
         if not ok:
             assert degenerate_ok and degenerate, \
