@@ -46,7 +46,7 @@ typedef int32_t rt_status;
 #define RT_MODE_FAST_F32 2    /* f32, near-child-first ordered traversal */
 
 const char *rt_last_error(void);
-/* library / build identification, e.g. "raytracer_amd 0.1 gfx950" */
+/* library / build identification, e.g. "raytracer_amd 0.3 gfx950" */
 const char *rt_version(void);
 
 /* ------------------------------------------------------------------ */

@@ -156,6 +156,11 @@ class Bvh:
 STATIC_WORKSPACE_BYTES = 64 << 20
 
 
+def version():
+    """The library's identification string (rt_version)."""
+    return lib().rt_version().decode()
+
+
 def workspace_bytes_per_path(light_sample_rays, bounce_limit):
     return int(lib().rt_workspace_bytes_per_path(light_sample_rays, bounce_limit))
 

@@ -36,7 +36,7 @@ using rt::fail;
 extern "C" {
 
 const char *rt_last_error(void) { return rt::last_error_text().c_str(); }
-const char *rt_version(void) { return "raytracer_amd 0.1 gfx950"; }
+const char *rt_version(void) { return "raytracer_amd 0.3 gfx950"; }
 
 void rt_free(void *p) { std::free(p); }
 

@@ -367,7 +367,15 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     float *my_park = park + threadIdx.x;
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t lane = lane_id();
-    uint2 *my_stack = lds_stack + (threadIdx.x >> 6) * (kStackLds * 64) + lane;
+    // The LDS part of the stack is laid out [entry][thread of the block], and a lane's
+    // stack pointer is kept as the BYTE offset of its next free entry from the start of
+    // that array (entry x 2048 + thread x 8): a push or pop then needs no address
+    // arithmetic beyond one add, and "is this entry in LDS" is one compare with a
+    // constant for every lane.
+    constexpr uint32_t kEntryStride = 256 * sizeof(uint2);       // bytes between a lane's consecutive entries
+    constexpr uint32_t kLdsLimit = kStackLds * kEntryStride;     // offsets below this are LDS entries
+    const uint32_t sp_empty = threadIdx.x * (uint32_t)sizeof(uint2);
+    char *const stack_bytes = reinterpret_cast<char *>(lds_stack);
     uint2 spill[kStackSpill];
     RayFeed feed;
     // origin and inverse direction, as the register pairs the packed slab step reads:
@@ -384,14 +392,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     // of this register.
     constexpr uint32_t kLaneIdle = 0xFFFFFFFEu;
     uint32_t where = kLaneIdle;
-    int32_t sp = 0;
+    uint32_t sp = sp_empty;      // byte offset of the next free stack entry (see above)
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0, c_wa = 0, c_wb = 0, c_lb = 0;
 
     auto push = [&](uint32_t ref, float tn) {
         const uint2 e = make_uint2(ref, (uint32_t)f2i(tn));
-        if (sp < kStackLds) my_stack[sp * 64] = e;
-        else if (sp < kStackTotal) spill[sp - kStackLds] = e;
-        sp++;   // deeper than both levels cannot happen: a wide tree whose depth x 3 exceeds the stack is not built
+        if (sp < kLdsLimit) *reinterpret_cast<uint2 *>(stack_bytes + sp) = e;
+        else if (sp < kStackTotal * kEntryStride) spill[sp / kEntryStride - kStackLds] = e;
+        sp += kEntryStride;   // deeper than both levels cannot happen: a wide tree whose depth x 3 exceeds the stack is not built
     };
     // Stands the lane on `ref`: an interior record, or a leaf.
     auto stand_on = [&](uint32_t ref) { where = ref; };
@@ -400,11 +408,11 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     // from the spill array only when the entry lives there, so that both accesses
     // keep their own address space.
     auto pop_next = [&]() {
-        while (sp > 0) {
-            sp--;
-            uint2 e = my_stack[(sp < kStackLds ? sp : kStackLds - 1) * 64];
+        while (sp >= kEntryStride) {
+            sp -= kEntryStride;
+            uint2 e = *reinterpret_cast<const uint2 *>(stack_bytes + (sp < kLdsLimit ? sp : sp_empty));
             asm volatile("" : "+v"(e.x), "+v"(e.y));   // the LDS read stays an LDS read
-            if (sp >= kStackLds) e = spill[sp - kStackLds];
+            if (sp >= kLdsLimit) e = spill[sp / kEntryStride - kStackLds];
             if (i2f((int32_t)e.y) <= h_lim) {
                 stand_on(e.x);
                 return;
@@ -442,7 +450,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 my_park[3 * 256] = b.x;
                 my_park[4 * 256] = b.y;
                 my_park[5 * 256] = b.z;
-                sp = 0;
+                sp = sp_empty;
                 stand_on(s.fast_root);
             }
             active = wave_ballot(where != kLaneIdle);

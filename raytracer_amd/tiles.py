@@ -68,12 +68,14 @@ def _paste_uniform(frame, buf, mine):
     return True
 
 
-def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None):
+def gather_static(local_rgba, tile_list, world, rank, frame=None, group=None, force_collective=False):
     """Static assignment: every rank holds the RGBA8 images of its block-cyclic
     tiles back to back in `local_rgba` (uint8, padded to the largest per-rank
     size).  One gather to rank 0, which pastes every tile at its offset into
-    `frame` ((H, W, 4) uint8).  Returns the frame on rank 0, None elsewhere."""
-    if world > 1:
+    `frame` ((H, W, 4) uint8).  Returns the frame on rank 0, None elsewhere.
+    `force_collective` runs the collective even in a group of one rank (tests
+    of the RCCL branch on a single GPU)."""
+    if world > 1 or force_collective:
         bufs = [torch.empty_like(local_rgba) for _ in range(world)] if rank == 0 else None
         dist.gather(local_rgba, bufs, dst=0, group=group)
     else:
@@ -97,40 +99,51 @@ def paste_tiles(frame, buf, tiles):
         off += w * h * 4
 
 
-def gather_dynamic(local_rgba, my_ids, tile_list, world, rank, frame, group=None):
+def gather_dynamic(local_rgba, my_ids, tile_list, world, rank, frame, group=None, force_collective=False):
     """Dynamic assignment: a rank holds the RGBA8 images of the tiles it happened
     to pull, back to back in pull order, and the list of their ids.  One small
     all-gather tells every rank who rendered what; then each rank sends exactly
     its own pixels to rank 0 (point to point, no padding to the worst case and
-    no full-frame reduction), which pastes them.  Returns the frame on rank 0."""
+    no full-frame reduction), which pastes them.  All receives of rank 0 and
+    every rank's send go out as ONE batch (`dist.batch_isend_irecv`: one RCCL
+    group), so that the peers' transfers run side by side, each over its own
+    xGMI link, instead of one after another.  Returns the frame on rank 0.
+    `force_collective` runs the all-gather and a send-to-self / receive-from-self
+    pair even in a group of one rank (tests of the RCCL branch on a single GPU)."""
     n_tiles = len(tile_list)
     dev = local_rgba.device
     ids = torch.full((n_tiles,), -1, dtype=torch.int32, device=dev)
     if my_ids:
         ids[:len(my_ids)] = torch.tensor(my_ids, dtype=torch.int32, device=dev)
-    if world > 1:
+    if world > 1 or force_collective:
         all_ids = [torch.empty_like(ids) for _ in range(world)]
         dist.all_gather(all_ids, ids, group=group)
     else:
         all_ids = [ids]
     my_bytes = sum(tile_list[i][3] * tile_list[i][4] for i in my_ids) * 4
+    self_loop = force_collective and rank == 0       # rank 0 also sends to itself instead of copying
+    ops, bufs, owned = [], [], None
+    if (rank != 0 or self_loop) and my_bytes:
+        ops.append(dist.P2POp(dist.isend, local_rgba[:my_bytes], 0, group))
+    if rank == 0:
+        owned = [[int(i) for i in t.tolist() if i >= 0] for t in all_ids]
+        seen = sorted(i for o in owned for i in o)
+        if seen != list(range(n_tiles)):
+            raise RuntimeError("the ranks' tile lists do not cover the frame exactly once")
+        for r in range(world):
+            if r == 0 and not self_loop:
+                bufs.append(local_rgba)
+                continue
+            nbytes = sum(tile_list[i][3] * tile_list[i][4] for i in owned[r]) * 4
+            buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            bufs.append(buf)
+            if nbytes:
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     if rank != 0:
-        if my_bytes:
-            dist.send(local_rgba[:my_bytes], dst=0, group=group)
         return None
-    owned = [[int(i) for i in t.tolist() if i >= 0] for t in all_ids]
-    seen = sorted(i for o in owned for i in o)
-    if seen != list(range(n_tiles)):
-        raise RuntimeError("the ranks' tile lists do not cover the frame exactly once")
-    bufs, reqs = [local_rgba], []
-    for r in range(1, world):
-        nbytes = sum(tile_list[i][3] * tile_list[i][4] for i in owned[r]) * 4
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        bufs.append(buf)
-        if nbytes:
-            reqs.append(dist.irecv(buf, src=r, group=group))
-    for q in reqs:
-        q.wait()
     for r in range(world):
         paste_tiles(frame, bufs[r], [tile_list[i] for i in owned[r]])
     return frame
@@ -144,10 +157,10 @@ def pull_chunk(n_tiles, world, samples_per_tile, target_samples=32 << 20):
     return max(1, min(want, n_tiles // max(1, 2 * world)))
 
 
-def sum_counters(values, device, world, group=None):
+def sum_counters(values, device, world, group=None, force_collective=False):
     """All-reduce of scalar counters (the frontend sums the workers' ray
     counters, Renderer.js:772-774).  Returns Python ints."""
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or force_collective:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return [int(round(v)) for v in t.tolist()]

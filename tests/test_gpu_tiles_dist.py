@@ -66,6 +66,19 @@ def test_two_ranks_on_one_gpu_compose_the_single_rank_frame(product_lib, gpu_dev
         assert int(got["ranks_with_work"]) == 2
 
 
+def test_exchange_helpers_over_rccl_in_a_group_of_one(product_lib, gpu_device):
+    """The RCCL branch of the exchange -- dist.gather, all_gather + one batched
+    isend/irecv group, all_reduce, all on cuda tensors -- executed for real: a
+    child process opens a `nccl` group of world size 1 on this GPU and forces
+    the helpers through their collective paths (tests/gpu_rccl_worker.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_rccl_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert "rccl ok" in out.stdout and "backend nccl" in out.stdout
+
+
 def test_bench_starts_its_own_ranks(product_lib, gpu_device):
     """`python bench.py --gpus 2` with no launcher around it must run two ranks
     (never one rank labelled as such): here on one GPU over gloo, on the small
@@ -79,6 +92,12 @@ def test_bench_starts_its_own_ranks(product_lib, gpu_device):
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
         doc = json.loads(line)
         assert doc["n_gpus"] == 2 and doc["value"] > 0
+        ranks = doc["ranks"]       # what each rank spent where, for attributing a shortfall at N ranks
+        assert len(ranks["render_ms_per_step"]) == 2 and len(ranks["gather_ms_per_step"]) == 2
+        assert sum(ranks["tiles_per_step"]) == doc["config"]["tiles"]
+        assert abs(sum(ranks["rays_per_step"]) - doc["config"]["rays_per_step"]) < 1
+        if extra:
+            assert min(ranks["pulls_per_step"]) >= 1
         assert doc["config"]["tile_assignment"] == ("dynamic pull queue" if extra else "block-cyclic")
     # asking for more GPUs than there are over RCCL is refused, not downgraded
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"],

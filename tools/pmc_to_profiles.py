@@ -2,8 +2,14 @@
 """Turns rocprofv3 --pmc counter passes over bench.py into the per-ray figures
 bench.py reads from profiles/:
 
-    pmc_to_profiles.py valu    DIR BENCH_LOG WORKLOAD MODE   -> profiles/r02_valu_per_ray.json
-    pmc_to_profiles.py traffic FETCH_DIR WRITE_DIR BENCH_LOG WORKLOAD MODE -> profiles/r02_traffic.json
+    pmc_to_profiles.py valu    DIR BENCH_LOG WORKLOAD MODE   -> profiles/<round>_valu_per_ray.json
+    pmc_to_profiles.py traffic FETCH_DIR WRITE_DIR BENCH_LOG WORKLOAD MODE -> profiles/<round>_traffic.json
+
+<round> is $RT_PROFILE_ROUND (default r03).  Every entry is stamped with what it
+was measured on: the library's rt_version(), the hash of the kernel sources
+(bench.py: kernel_source_sha, the same hash bench.py compares against when it
+reads the entry) and the git commit given in $RT_GIT_HEAD (the GPU box has no
+.git; the caller passes `git rev-parse --short HEAD`).
 
 DIR holds the counter CSVs of ONE run of `bench.py --steps 1 --warmup 0 ...`
 (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE in
@@ -31,6 +37,16 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("RT_PROFILE_ROUND", "r03")
+
+
+def provenance():
+    """What the counters were measured on (see the module docstring)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from raytracer_amd import api
+    return {"git_head": os.environ.get("RT_GIT_HEAD") or None, "rt_version": api.version(),
+            "kernel_source_sha": bench.kernel_source_sha()}
 
 
 def timed_kernel(name, mode):
@@ -60,6 +76,7 @@ def bench_line(path):
 def merge(fname, workload, mode, entry):
     path = os.path.join(ROOT, "profiles", fname)
     data = json.load(open(path)) if os.path.exists(path) else {}
+    entry.update(provenance())
     data.setdefault(workload, {})[mode] = entry
     with open(path, "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
@@ -73,7 +90,7 @@ def main():
         c, n = sums(d, mode)
         doc = bench_line(log)
         rays = doc["config"]["rays_per_step"] * doc["steps"]
-        merge("r02_valu_per_ray.json", workload, mode, {
+        merge(f"{ROUND}_valu_per_ray.json", workload, mode, {
             "command": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE ... -- "
                        f"python3 bench.py --workload {workload} --mode {mode} --steps 1 --warmup 0 --spp {doc['config']['spp']} --cpu-seconds 0",
             "kernel": doc["roofline"]["kernel"], "dispatches": n, "rays": rays,
@@ -97,7 +114,7 @@ def main():
         rays = doc["config"]["rays_per_step"] * doc["steps"]
         fetch = f.get("FETCH_SIZE", f.get("FETCH_SIZE_sum", 0.0))
         write = w.get("WRITE_SIZE", w.get("WRITE_SIZE_sum", 0.0))
-        merge("r02_traffic.json", workload, mode, {
+        merge(f"{ROUND}_traffic.json", workload, mode, {
             "command": f"rocprofv3 --pmc FETCH_SIZE (and, in a run of its own, WRITE_SIZE) -- python3 bench.py --workload "
                        f"{workload} --mode {mode} --steps 1 --warmup 0 --spp {doc['config']['spp']} --cpu-seconds 0",
             "kernel": doc["roofline"]["kernel"], "dispatches": n, "rays": rays,
