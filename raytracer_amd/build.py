@@ -52,5 +52,23 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+RCP_CHECK_SRC = os.path.join(os.path.dirname(HERE), "tools", "ubench", "rcp_check.hip")
+RCP_CHECK_BIN = os.path.join(os.path.dirname(HERE), "tools", "ubench", "rcp_check")
+
+
+def build_rcp_check(force=False):
+    """The exhaustive check of the triangle test's short reciprocal (rt_core.h:
+    recip_det) as a small program of its own; the GPU tests run it."""
+    if (not force and os.path.exists(RCP_CHECK_BIN)
+            and os.path.getmtime(RCP_CHECK_BIN) >= os.path.getmtime(RCP_CHECK_SRC)):
+        return RCP_CHECK_BIN
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off",
+                           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result",
+                           RCP_CHECK_SRC, "-o", RCP_CHECK_BIN])
+    return RCP_CHECK_BIN
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_rcp_check(force="--force" in sys.argv))

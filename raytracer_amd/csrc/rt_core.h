@@ -61,8 +61,8 @@ struct DevScene {
     // layout (may be null): (min.xyz, bits next)(max.xyz, bits w).  Interior:
     // next = where to go when the box fails, w = -1 - index of the left child.
     // Leaf: next = where to go after the leaf, w = count << 24 | first triangle.
-    // The n_top nodes nearest the root come first in the array so that a block
-    // can keep them in LDS.
+    // The n_top nodes with the largest boxes (a top of the tree) come first in
+    // the array so that a block can keep them in LDS.
     const f4 *linked;
     int32_t n_top;
     const f4 *tris;
@@ -152,6 +152,33 @@ RT_HD bool slab(const Ray<Real> &r, const f4 &lo, const f4 &hi, Real &otmin, Rea
     return true;
 }
 
+// 1 / det of the triangle test (triangle.go:86), correctly rounded.  On the
+// device a float32 determinant takes a short path: the hardware reciprocal
+// (1 ulp) and two Newton steps in fused arithmetic, five instructions instead
+// of the ten of the compiler's division, which also scales denormal and huge
+// operands.  The short form equals the IEEE quotient for EVERY float in
+// [5e-5, 2^100] (compared exhaustively on the GPU by tools/ubench/rcp_check.hip,
+// which the GPU tests run); the cull has rejected determinants below 1e-4
+// before the quotient is used, and larger ones (or NaN) take the division.
+template <typename Real>
+RT_HD Real recip_det(Real det) {
+    return (Real)1.0 / det;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+RT_HD float recip_det<float>(float det) {
+    float r = __builtin_amdgcn_rcpf(det);
+    r = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
+    r = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
+    // a vote of the wave, so that the division's ten instructions sit behind a scalar
+    // branch that is all but never taken instead of being computed and masked out
+    const bool wide_range = !(det <= 0x1p100f);
+    if (__builtin_amdgcn_ballot_w64(wide_range) != 0)
+        r = wide_range ? 1.0f / det : r;
+    return r;
+}
+#endif
+
 template <typename Real>
 struct Hit {
     Real t, u, v;
@@ -177,7 +204,7 @@ RT_HD bool tri_test(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2
     const Real pz = r.dx * wy - r.dy * wx;
     const Real det = ex * px + ey * py + ez * pz;
     if (det < (Real)0.0001f) return true;
-    const Real invdet = (Real)1.0 / det;
+    const Real invdet = recip_det(det);
     const Real tx = r.ox - (Real)q0.w, ty = r.oy - (Real)q1.x, tz = r.oz - (Real)q1.y;
     const Real u = (tx * px + ty * py + tz * pz) * invdet;
     if (u < 0 || u > 1) return true;
@@ -215,7 +242,7 @@ RT_HD bool tri_eval(const Ray<Real> &r, const f4 &q0, const f4 &q1, const f4 &q2
     const Real py = r.dz * wx - r.dx * wz;
     const Real pz = r.dx * wy - r.dy * wx;
     const Real det = ex * px + ey * py + ez * pz;
-    const Real invdet = (Real)1.0 / det;
+    const Real invdet = recip_det(det);
     const Real tx = r.ox - (Real)q0.w, ty = r.oy - (Real)q1.x, tz = r.oz - (Real)q1.y;
     u = (tx * px + ty * py + tz * pz) * invdet;
     const Real qx = ty * ez - tz * ey;

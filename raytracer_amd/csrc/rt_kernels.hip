@@ -142,12 +142,13 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 // ---------------------------------------------------------------------------
 
 // TOP: the tree is read through its linked view (DevScene::linked), whose
-// first n_top nodes -- the whole levels nearest the root that fit kTopNodes
-// records, the most fetched nodes of the tree -- are copied into LDS by every
-// block: the kernel is bound by the number of per-lane global loads.  A copy is
-// shared by the 16 waves of a 1024-thread block (80 KB, two blocks per CU fill its
-// 160 KB of LDS); with 256-thread blocks the same LDS held eight copies of a fifth
-// as many nodes.
+// first n_top nodes -- the kTopNodes nodes with the largest boxes, which
+// link_nodes moves to the front of the array: a parent's box is never smaller
+// than its child's, so they form a top of the tree, and area is how likely a ray
+// is to reach a node -- are copied into LDS by every block: the kernel is bound
+// by the number of per-lane global loads.  A copy is shared by the 16 waves of a
+// 1024-thread block (80 KB, two blocks per CU fill its 160 KB of LDS); with
+// 256-thread blocks the same LDS held eight copies of a fifth as many nodes.
 // Visit order and arithmetic are the same.
 constexpr int kTopNodes = 2560;
 constexpr int kTopBlock = 1024;
@@ -221,8 +222,10 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
                     lo = top[2 * node];
                     hi = top[2 * node + 1];
                 } else {
-                    lo = s.linked[2 * node];
-                    hi = s.linked[2 * node + 1];
+                    // 32-bit byte offset beside the scalar base (a linked view has fewer than 2^25 nodes)
+                    const f4 *q = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.linked) + ((uint32_t)node << 5));
+                    lo = q[0];
+                    hi = q[1];
                 }
             } else {
                 lo = s.nodes[2 * node];
@@ -275,8 +278,18 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             // two triangles per step, fetched together so that their loads overlap,
             // tested in array order
             const bool two = leaf_n > 1;
-            const f4 *qa = s.tris + 3 * (size_t)leaf_a;
-            const f4 *qb = qa + (two ? 3 : 0);
+            const f4 *qa, *qb;
+            if (TOP) {
+                // 32-bit byte offsets beside the scalar base (triangle positions of a linked view are below 2^24)
+                const uint32_t off_a = (uint32_t)leaf_a * 48u;
+                uint32_t off_b = off_a + (two ? 48u : 0u);
+                asm volatile("" : "+v"(off_b));
+                qa = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_a);
+                qb = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_b);
+            } else {
+                qa = s.tris + 3 * (size_t)leaf_a;
+                qb = qa + (two ? 3 : 0);
+            }
             const f4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
             const f4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
             if (COUNT) c_fetch += two ? 2 : 1;
@@ -677,6 +690,83 @@ __device__ __forceinline__ v3 fold_shadows(const DevScene &s, const PassParams &
               gomath::clamp01(shading.z * invl)};
 }
 
+// One try of RandomInUnitSphere (utility.go:34-48) on the counter RNG: the point
+// made of draws c, c + 1, c + 2 of a stream.
+__device__ __forceinline__ v3 sphere_try(uint64_t stream, uint32_t c) {
+    v3 p;
+    p.x = rng_f32(stream, c) * 2 - 1;
+    p.y = rng_f32(stream, c + 1) * 2 - 1;
+    p.z = rng_f32(stream, c + 2) * 2 - 1;
+    return p;
+}
+
+// random_in_hemisphere's rejection loop (rt_core.h) for the lanes of a wave whose
+// `need` is set, with the tries shared out over the whole wave.  A try costs three
+// 64-bit hash draws and succeeds with probability pi/6: run lane by lane, a lane is
+// done after 1.9 tries on average, but the wave waits for its unluckiest lane
+// (about 6.5 tries).  The RNG is counter based, so try j of any path can be
+// evaluated by any lane: after one try of its own per lane, every further round
+// deals the still open paths' next tries to ALL 64 lanes (open path of rank r gets
+// the lanes r, r + n, r + 2n, ... when n paths are open) and each path takes its
+// first accepted try in try order.  Result and draw count per path are exactly
+// those of the sequential loop: the first try j with |p|^2 < 1, 3 (j + 1) draws
+// consumed; try 63 is taken in any case, halved (the loop's bound).
+// Every lane of the wave must call this (the exec mask must be full).
+__device__ __forceinline__ v3 wave_random_in_unit_sphere(bool need, uint64_t stream, uint32_t &ctr) {
+    const uint32_t lane = lane_id();
+    const uint32_t c0 = ctr;
+    v3 p = sphere_try(stream, c0);
+    bool open = need && !(lensqr(p) < 1);
+    uint32_t used = 1;          // tries the lane's own path has consumed once it is closed
+    uint32_t tried = 1;         // wave-uniform: tries evaluated so far for every open path
+    uint64_t pending = wave_ballot(open);
+    while (pending != 0) {
+        const uint32_t n = (uint32_t)__popcll(pending);
+        uint32_t m = 64u / n;                                   // tries per open path this round
+        if (m > (uint32_t)kHemiMaxTries - tried) m = (uint32_t)kHemiMaxTries - tried;
+        // the open path of rank r announces its lane to lane r (the other lanes fill the rest
+        // of the permutation, so that every destination is written exactly once)
+        const uint32_t rank = (uint32_t)__popcll(pending & lanemask_lt());
+        const uint32_t dest = open ? rank : n + (uint32_t)__popcll(~pending & lanemask_lt());
+        const int lane_of_rank = __builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+        // this lane works for rank r = lane mod n on try `tried + lane / n`; (lane + 1/2) / n
+        // keeps the approximate reciprocal's error away from the integers
+        const uint32_t q = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)n));
+        const uint32_t r = lane - q * n;
+        const int target = __builtin_amdgcn_ds_bpermute((int)(r << 2), lane_of_rank) << 2;
+        const uint32_t t_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(target, (int)(uint32_t)stream);
+        const uint32_t t_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(target, (int)(uint32_t)(stream >> 32));
+        const uint32_t t_c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(target, (int)c0);
+        const uint32_t j = tried + q;
+        v3 w = sphere_try(((uint64_t)t_hi << 32) | t_lo, t_c0 + 3u * j);
+        bool ok = lensqr(w) < 1;
+        if (j == (uint32_t)kHemiMaxTries - 1 && !ok) {          // the bounded loop's last try is taken, halved
+            w = v3{w.x * 0.5f, w.y * 0.5f, w.z * 0.5f};
+            ok = true;
+        }
+        const uint64_t got = wave_ballot(q < m && ok);
+        // the tries of the path of rank r sit in lanes r, r + n, ..., r + (m - 1) n, in try order
+        uint64_t every_nth = 0;
+        for (uint32_t i = 0; i < m; ++i) every_nth |= 1ull << (n * i);     // wave-uniform
+        const uint64_t mine = (got >> rank) & every_nth;
+        const bool closes = open && mine != 0;
+        const int src = (int)((closes ? rank + (uint32_t)__ffsll((unsigned long long)mine) - 1u : lane) << 2);
+        const float wx = i2f(__builtin_amdgcn_ds_bpermute(src, f2i(w.x)));
+        const float wy = i2f(__builtin_amdgcn_ds_bpermute(src, f2i(w.y)));
+        const float wz = i2f(__builtin_amdgcn_ds_bpermute(src, f2i(w.z)));
+        const uint32_t wj = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)j);
+        if (closes) {
+            p = v3{wx, wy, wz};
+            used = wj + 1;
+            open = false;
+        }
+        tried += m;
+        pending = wave_ballot(open);
+    }
+    if (need) ctr = c0 + 3u * used;
+    return p;
+}
+
 // Path vertex k.  Reads queue (k & 1), writes queue ((k+1) & 1).
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
@@ -741,16 +831,17 @@ k_shade(DevScene s, PassParams p, Batch b, PathBuffers w, int k) {
     }
 
     // bounce (trace.go:81-108)
-    bool bounce = false;
-    v3 sample{0, 0, 0};
-    if (at_vertex) {
-        if (k >= p.B) {
-            w.terms_a[(size_t)k * P + id] = f4{prev_shading.x, prev_shading.y, prev_shading.z, 0.0f};
-            reinterpret_cast<uint2 *>(w.head + id)[1] = make_uint2(pack_head(kLastVertex, (uint32_t)k + 1, ctr), 0u);
-        } else {
-            sample = normalize(random_in_hemisphere(stream, ctr, normal));
-            bounce = true;
-        }
+    const bool bounce = at_vertex && k < p.B;
+    if (at_vertex && !bounce) {
+        w.terms_a[(size_t)k * P + id] = f4{prev_shading.x, prev_shading.y, prev_shading.z, 0.0f};
+        reinterpret_cast<uint2 *>(w.head + id)[1] = make_uint2(pack_head(kLastVertex, (uint32_t)k + 1, ctr), 0u);
+    }
+    // utility.go:50-70: a point in the unit ball, flipped into the normal's hemisphere
+    // (every lane takes part in the draw, see wave_random_in_unit_sphere)
+    v3 sample = wave_random_in_unit_sphere(bounce, stream, ctr);
+    if (bounce) {
+        if (!(dot(sample, normal) > 0.0f)) sample = v3{sample.x * -1, sample.y * -1, sample.z * -1};
+        sample = normalize(sample);
     }
     const uint32_t bq = block_append(out_count, bounce, p.L);
     if (w.path_rays && at_vertex) w.path_rays[id] += cast_here + (bounce ? 1u : 0u);
@@ -942,7 +1033,7 @@ struct DeviceGuard {
 static bool link_nodes(const Bvh &bvh, const std::vector<float> &nodes, int32_t max_top,
                        std::vector<float> &out, int32_t &n_top) {
     const int32_t nn = bvh.n_nodes;
-    if (nn <= 0 || (int64_t)nn >= (1 << 30)) return false;
+    if (nn <= 0 || (int64_t)nn >= (1 << 27)) return false;   // the kernel addresses the records with 32-bit byte offsets
     // the max_top nodes with the largest boxes: the chance that a ray reaches a node
     // grows with its box's area, and a parent's box is never smaller than its
     // child's, so these are the most fetched nodes and form a top of the tree

@@ -1,6 +1,8 @@
 """GPU parity of the batch ray cast (rt_trace_rays through the C ABI) against
 the oracle: hit ids, t, u, v bit-exact in the float32 and float64 modes, the
 traversal counters, and the edge cases of the domain."""
+import os
+
 import numpy as np
 import pytest
 
@@ -429,3 +431,20 @@ def test_trace_call_captured_into_a_graph_replays(soup20k):
             torch.cuda.synchronize()
             got = d_hits.cpu().numpy().view(api.HIT_DTYPE).reshape(-1)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mode
+
+
+def test_short_reciprocal_of_the_triangle_test_is_the_ieee_quotient(product_lib, gpu_device):
+    """rt_core.h: recip_det takes the hardware reciprocal plus two fused Newton
+    steps for determinants in [1e-4, 2^100] instead of the ten-instruction
+    division.  tools/ubench/rcp_check compares that sequence with 1.0f / x for
+    every float32 in [5e-5, 2^100] on the GPU it runs on: no mismatch allowed
+    (triangle.go:86 divides; the bit-exact modes need the IEEE quotient)."""
+    import json
+    import subprocess
+    from raytracer_amd import build
+    exe = build.RCP_CHECK_BIN
+    assert os.path.exists(exe), "tools/ubench/rcp_check is built by __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    doc = json.loads(out.stdout.strip().splitlines()[-1])
+    assert doc["mismatches"] == 0 and doc["floats_checked"] > 900_000_000
