@@ -44,6 +44,16 @@ typedef int32_t rt_status;
 #define RT_MODE_STRICT_F32 0  /* reference arithmetic and visit order; bit-exact */
 #define RT_MODE_FP64 1        /* same control flow in float64 (validation) */
 #define RT_MODE_FAST_F32 2    /* f32, near-child-first ordered traversal */
+/* The same ordered traversal for rays that START within one scene diagonal of
+ * the scene's bounding box (rt_scene_info: near_lo, near_hi): the step decodes
+ * a record's planes relative to the ray origin, one packed instruction less per
+ * plane pair, and the planes are kept far enough outside their boxes that the
+ * box tests stay on the safe side of the reference's for such rays.  The
+ * caller promises the region; a ray from farther away may miss a hit that
+ * grazes a box.  The render entry points choose this form by themselves when
+ * they are given RT_MODE_FAST_F32 and every camera ray starts in the region
+ * (all other rays of a path start on the scene's surfaces). */
+#define RT_MODE_FAST_NEAR_F32 3
 
 const char *rt_last_error(void);
 /* library / build identification, e.g. "raytracer_amd 0.3 gfx950" */
@@ -158,6 +168,8 @@ typedef struct rt_scene_info {
      * did not fit device memory or the workspace limit), and the bytes of path
      * workspace the scene holds right now */
     uint64_t max_paths_in_flight, workspace_bytes;
+    /* the box ray origins must lie in for RT_MODE_FAST_NEAR_F32 */
+    float near_lo[3], near_hi[3];
 } rt_scene_info;
 
 /* context.go:172-226 on the host, no device needed: the area light of a mesh.

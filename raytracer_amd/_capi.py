@@ -36,7 +36,8 @@ class SceneInfo(C.Structure):
                 ("total_device_bytes", C.c_uint64), ("ordered_bytes", C.c_uint64),
                 ("linked_view", C.c_int32),
                 ("ordered_view", C.c_int32),
-                ("max_paths_in_flight", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+                ("max_paths_in_flight", C.c_uint64), ("workspace_bytes", C.c_uint64),
+                ("near_lo", C.c_float * 3), ("near_hi", C.c_float * 3)]
 
 
 class Stats(C.Structure):

@@ -13,6 +13,7 @@ from ._capi import Pass, Stats, check, lib
 MODE_STRICT_F32 = 0
 MODE_FP64 = 1
 MODE_FAST_F32 = 2
+MODE_FAST_NEAR_F32 = 3      # ordered traversal, rays starting within a scene diagonal of the scene's box
 
 RAY_DTYPE = np.dtype([("origin", np.float32, 3), ("tmax", np.float32),
                       ("dir", np.float32, 3), ("pad", np.float32)])
@@ -226,7 +227,8 @@ class Scene:
     def info(self):
         out = _capi.SceneInfo()
         check(lib().rt_scene_info_get(self._h, C.byref(out)))
-        return {n: getattr(out, n) for n, _ in out._fields_}
+        vals = {n: getattr(out, n) for n, _ in out._fields_}
+        return {n: (list(v) if isinstance(v, C.Array) else v) for n, v in vals.items()}
 
     def light(self):
         out = _capi.Light()

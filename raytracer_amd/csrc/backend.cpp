@@ -267,7 +267,7 @@ void rtb_set_progress_callback(rtb_context *ctx, rtb_progress_fn fn, void *user)
 
 rt_status rtb_set_mode(rtb_context *ctx, int32_t mode) {
     if (!ctx) return fail(RT_ERR_INVALID, "context is NULL");
-    if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FP64 && mode != RT_MODE_FAST_F32)
+    if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FP64 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FAST_NEAR_F32)
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
     ctx->mode = mode;
     return RT_OK;

@@ -263,6 +263,10 @@ rt_status rt_scene_info_get(const rt_scene *scene, rt_scene_info *out) {
     out->node_bytes = s.node_bytes;
     out->tri_bytes = s.tri_bytes;
     out->ordered_bytes = s.wide_bytes;
+    for (int a = 0; a < 3; ++a) {
+        out->near_lo[a] = s.near_lo[a];
+        out->near_hi[a] = s.near_hi[a];
+    }
     out->linked_view = s.d_linked ? 1 : 0;
     out->ordered_view = s.d_wide ? 1 : 0;
     out->total_device_bytes = s.node_bytes * (s.d_linked ? 2 : 1) + s.wide_bytes + s.tri_bytes +

@@ -51,6 +51,15 @@ struct WideBuilder {
     std::vector<float> &recs;
     std::vector<BNode> bin;
     int32_t max_wide_depth = 0;
+    // Every decoded plane keeps this distance, per axis, from the box it bounds (lower
+    // planes below, upper planes above).  The near-origin form of the traversal step
+    // (rt_core.h: kNearOriginDiagonals) subtracts the ray origin from the record's frame
+    // origin BEFORE it decodes a plane: d = fl(origin - o), plane - o = fma(offset, step,
+    // d).  The one rounding of d errs by at most 2^-24 |origin - o|, so a plane that
+    // lies at least that far outside the true box still yields a slab distance on the
+    // safe side of the reference's (bound - o) * invDir (rounding is monotone).  The
+    // margin is 2^-23 times the largest |origin - o| a qualifying ray can have.
+    float margin[3] = {0, 0, 0};
 
     // bounds of the triangles at array positions [start, start+count)
     void range_box(int32_t start, int32_t count, float mn[3], float mx[3]) const {
@@ -214,8 +223,13 @@ struct WideBuilder {
                 if (c.mx[a] > hi) hi = c.mx[a];
             }
             if (n == 0) { lo = 0; hi = 0; }
+            // the frame starts a margin below the lowest child plane, rounded down
+            const double m = (double)margin[a];
+            float fo = (float)((double)lo - m);
+            if ((double)fo > (double)lo - m) fo = std::nextafter(fo, -std::numeric_limits<float>::infinity());
+            lo = fo;
             origin[a] = lo;
-            const float ext = hi - lo;
+            const float ext = (float)(((double)hi + m) - (double)lo) * 1.0000002f;
             // smallest step s with 255 * s >= ext that the check below accepts (any float, not only a
             // power of two: the decode is one fma either way); a floor keeps empty extents finite
             float s = ext > 0 ? ext / 255.0f : 0.0f;
@@ -224,21 +238,29 @@ struct WideBuilder {
                 bool ok = true;
                 for (int i = 0; i < n && ok; ++i) {
                     const BNode &c = bin[(size_t)kids[i]];
-                    // lower plane: largest q with decode(q) <= bound
-                    float x = std::floor((c.mn[a] - lo) / s);
-                    if (x < 0) x = 0;
+                    // A plane at offset q lies at q * s + lo exactly (a product of two floats plus
+                    // a float is exact in double arithmetic for these magnitudes); the decode
+                    // fma(q, s, lo) rounds that value to a float, and rounding never crosses the
+                    // box's own float bound, so a plane that is outside by the margin in exact
+                    // arithmetic also decodes outward.
+                    auto exact = [&](int q) { return (double)q * (double)s + (double)lo; };
+                    // lower plane: largest q whose plane lies at least the margin below the bound
+                    const double want_lo = (double)c.mn[a] - m;
+                    float x = std::floor((float)((want_lo - (double)lo) / (double)s));
+                    if (!(x >= 0)) x = 0;
                     if (x > 255) x = 255;
                     int q = (int)x;
-                    while (q > 0 && std::fmaf((float)q, s, lo) > c.mn[a]) --q;
-                    if (std::fmaf((float)q, s, lo) > c.mn[a]) ok = false;
+                    while (q > 0 && exact(q) > want_lo) --q;
+                    if (exact(q) > want_lo || std::fmaf((float)q, s, lo) > c.mn[a]) ok = false;
                     qlo[i][a] = (uint8_t)q;
-                    // upper plane: smallest q with decode(q) >= bound
-                    x = std::ceil((c.mx[a] - lo) / s);
-                    if (x < 0) x = 0;
+                    // upper plane: smallest q whose plane lies at least the margin above the bound
+                    const double want_hi = (double)c.mx[a] + m;
+                    x = std::ceil((float)((want_hi - (double)lo) / (double)s));
+                    if (!(x >= 0)) x = 0;
                     if (x > 255) { ok = false; x = 255; }
                     q = (int)x;
-                    while (q < 255 && std::fmaf((float)q, s, lo) < c.mx[a]) ++q;
-                    if (std::fmaf((float)q, s, lo) < c.mx[a]) ok = false;
+                    while (q < 255 && exact(q) < want_hi) ++q;
+                    if (exact(q) < want_hi || std::fmaf((float)q, s, lo) < c.mx[a]) ok = false;
                     qhi[i][a] = (uint8_t)q;
                 }
                 if (ok || !std::isfinite(s)) { step[a] = s; break; }
@@ -288,8 +310,24 @@ void build_wide(const rt_mesh &mesh, const Bvh &bvh, const std::vector<int32_t> 
     out.fast_ok = false;
     out.fast_root = 0;
     if (mesh.n_tris > rtc::kFastMaxTris || bvh.max_depth > 60) return;
-    WideBuilder b{mesh, bvh, skip, out.wide, {}, 0};
+    WideBuilder b{mesh, bvh, skip, out.wide, {}, 0, {0, 0, 0}};
     b.bin.reserve((size_t)bvh.n_nodes * 2);
+    {
+        // rays of the near-origin form start within kNearOriginDiagonals scene diagonals of
+        // the scene's box (the root's), a record's frame origin lies inside that box: on
+        // every axis |origin - o| is at most the box's extent plus that many diagonals
+        const float *mn = &bvh.bmin[0], *mx = &bvh.bmax[0];
+        double diag2 = 0;
+        for (int a = 0; a < 3; ++a) diag2 += ((double)mx[a] - mn[a]) * ((double)mx[a] - mn[a]);
+        const double diag = std::sqrt(diag2);
+        for (int a = 0; a < 3; ++a) {
+            const double reach = ((double)mx[a] - mn[a]) + (double)rtc::kNearOriginDiagonals * diag;
+            const double m = std::isfinite(reach) ? reach * 0x1p-23 : 0.0;
+            b.margin[a] = (float)m;
+            out.near_lo[a] = (float)((double)mn[a] - (double)rtc::kNearOriginDiagonals * diag);
+            out.near_hi[a] = (float)((double)mx[a] + (double)rtc::kNearOriginDiagonals * diag);
+        }
+    }
     const int32_t root = b.import_tree();
     const WideBuilder::BNode &rn = b.bin[(size_t)root];
     if (rn.left < 0) {

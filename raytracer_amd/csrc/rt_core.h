@@ -84,7 +84,8 @@ struct DevScene {
     //   [12..15] child refs: interior -> record index; leaf -> kLeafBit | count << 24
     //            | first triangle; unused slot -> kLeafBit (count 0)
     // A plane decodes as fma(offset, step, origin); decoded boxes contain the
-    // binary tree's boxes (lower planes rounded down, upper planes up).
+    // binary tree's boxes (lower planes rounded down, upper planes up) with a
+    // small margin to spare (flatten.cpp: margin) for the near-origin form.
     const f4 *wide;
     uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
     int32_t fast_ok;            // 0: tree does not fit the fast encoding
@@ -114,6 +115,16 @@ constexpr int32_t kFastMaxTris = (1 << 24) - 2;
 // distance, or at it from an earlier position.  FLT_MAX times the factor is
 // +inf, which admits every finite entry distance, as FLT_MAX itself does.
 constexpr float kTieSlack = 1.0f + 0x1p-18f;
+// Ordered traversal, near-origin form (RT_MODE_FAST_NEAR_F32): for rays that
+// start within this many scene diagonals of the scene's bounding box the step
+// subtracts the ray origin from the record's frame origin once per record and
+// decodes every plane relative to the ray, (offset * step + (origin - o)) *
+// invDir: two packed instructions per plane pair instead of three.  The
+// flattener keeps every decoded plane far enough outside its box (flatten.cpp:
+// margin) that the form stays on the safe side of the reference's box test for
+// such rays.  Every ray of a path traced from a camera in that region
+// qualifies: the others start on the scene's surfaces.
+constexpr int kNearOriginDiagonals = 1;
 
 // ---------------------------------------------------------------------------
 // Ray state for the reference-order traversal.
@@ -318,7 +329,7 @@ RT_HD void wide_sort4(float key[4], uint32_t ref[4]) {
 #undef RT_CE
 }
 
-template <bool COUNT>
+template <bool COUNT, bool NEAR = false>
 RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &h, Counters *c) {
     uint32_t stack_ref[kFastStackEntries];
     float stack_t[kFastStackEntries];
@@ -339,13 +350,19 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 pn[a] = inv[a] < 0 ? ph : pl;
                 pf[a] = inv[a] < 0 ? pl : ph;
             }
+            // near-origin form: the frame origin relative to the ray, rounded once per record
+            const float rel[3] = {q[0] - org[0], q[1] - org[1], q[2] - org[2]};
             for (int k = 0; k < 4; ++k) {
                 float tna[3], tfa[3];
                 for (int a = 0; a < 3; ++a) {
-                    const float bn = fmaf((float)((pn[a] >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
-                    const float bf = fmaf((float)((pf[a] >> (8 * k)) & 0xFFu), q[3 + a], q[a]);
-                    tna[a] = (bn - org[a]) * inv[a];
-                    tfa[a] = (bf - org[a]) * inv[a];
+                    const float on = (float)((pn[a] >> (8 * k)) & 0xFFu), of = (float)((pf[a] >> (8 * k)) & 0xFFu);
+                    if (NEAR) {
+                        tna[a] = fmaf(on, q[3 + a], rel[a]) * inv[a];
+                        tfa[a] = fmaf(of, q[3 + a], rel[a]) * inv[a];
+                    } else {
+                        tna[a] = (fmaf(on, q[3 + a], q[a]) - org[a]) * inv[a];
+                        tfa[a] = (fmaf(of, q[3 + a], q[a]) - org[a]) * inv[a];
+                    }
                 }
                 const float tn = fmaxf(fmaxf(tna[0], tna[1]), tna[2]);
                 const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);

@@ -86,6 +86,7 @@ struct Scene {
     rtc::f4 *d_wide = nullptr;        // ordered-traversal records (fast mode), may be null
     uint32_t fast_root = 0;
     uint64_t wide_bytes = 0;
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};   // origin region of the near-origin ordered form
     rtc::f4 *d_tri_shade = nullptr;   // per triangle (normal, material word)
     float *d_kd = nullptr;
     float *d_tri_uv = nullptr;

@@ -71,6 +71,9 @@ struct FlatScene {
     std::vector<float> wide;       // ordered-traversal records, 16 floats each (may be empty)
     uint32_t fast_root = 0;
     bool fast_ok = false;
+    // the region ray origins must lie in for the near-origin form of the ordered
+    // traversal: the scene's box grown by rtc::kNearOriginDiagonals diagonals
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};
 };
 rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out);
 const std::string &last_error_text();

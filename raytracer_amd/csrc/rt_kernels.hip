@@ -365,7 +365,24 @@ __device__ __forceinline__ void slab_planes(f2 &tx, f2 &ty, f2 &tz, f2 f_oxy, f2
         : "v"(f_oxy), "v"(f_ozsx), "v"(f_syz), "v"(r_oxy), "v"(r_ozix), "v"(r_iyz));
 }
 
-template <bool COUNT, int kStackLds>
+// The near-origin form (rt_core.h: kNearOriginDiagonals): the plane offsets are
+// decoded relative to the ray, offset * step + (frame origin - ray origin), with
+// that difference formed once per record, so the per-child subtraction is gone.
+// d_xy = (origin - o).xy; d_zsx = ((origin - o).z, step x).
+__device__ __forceinline__ void slab_planes_near(f2 &tx, f2 &ty, f2 &tz, f2 d_xy, f2 d_zsx, f2 f_syz,
+                                                 f2 r_ozix, f2 r_iyz) {
+    asm("v_pk_fma_f32 %0, %0, %4, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %2, %5, %4 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_mul_f32 %0, %0, %6 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %1, %1, %7 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %2, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "s_nop 0"
+        : "+v"(tx), "+v"(ty), "+v"(tz)
+        : "v"(d_xy), "v"(d_zsx), "v"(f_syz), "v"(r_ozix), "v"(r_iyz));
+}
+
+template <bool COUNT, int kStackLds, bool NEAR = false>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
@@ -509,6 +526,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // step x = (q0.z,q0.w), step y|z = (q1.x,q1.y); the ray likewise
             // (origin x|y), (origin z, 1/dir x), (1/dir y|z).
             const f2 f_oxy{q0.x, q0.y}, f_ozsx{q0.z, q0.w}, f_syz{q1.x, q1.y};
+            // near-origin form: the frame origin relative to the ray, once per record
+            const f2 d_xy{f_oxy.x - r_oxy.x, f_oxy.y - r_oxy.y}, d_zsx{f_ozsx.x - r_ozix.x, f_ozsx.y};
             float key[4];
             uint32_t ref[4] = {(uint32_t)f2i(q3.x), (uint32_t)f2i(q3.y), (uint32_t)f2i(q3.z), (uint32_t)f2i(q3.w)};
 #define RT_BYTE(v, k) ((float)(((v) >> (8 * (k))) & 0xFFu))
@@ -517,7 +536,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 f2 tx{RT_BYTE(plx, k), RT_BYTE(phx, k)};                                    \
                 f2 ty{RT_BYTE(ply, k), RT_BYTE(phy, k)};                                    \
                 f2 tz{RT_BYTE(plz, k), RT_BYTE(phz, k)};                                    \
-                slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);        \
+                if (NEAR) slab_planes_near(tx, ty, tz, d_xy, d_zsx, f_syz, r_ozix, r_iyz);  \
+                else slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);   \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
                 /* tn <= tf && tn <= h_lim && tf > 0 with one compare less (unused slot: inverted box) */ \
@@ -1143,6 +1163,8 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
         if ((st = upload(&sc->d_wide, flat.wide.data(), flat.wide.size() * 4)) != RT_OK) return st;
         sc->fast_root = flat.fast_root;
         sc->wide_bytes = flat.wide.size() * 4;
+        std::memcpy(sc->near_lo, flat.near_lo, sizeof sc->near_lo);
+        std::memcpy(sc->near_hi, flat.near_hi, sizeof sc->near_hi);
     }
     if ((st = upload(&sc->d_cursors, nullptr, (size_t)kCursorSlots * kCursorStride * sizeof(uint32_t))) != RT_OK) return st;
     HIP_TRY(hipMemset(sc->d_cursors, 0, (size_t)kCursorSlots * kCursorStride * sizeof(uint32_t)));
@@ -1318,16 +1340,26 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     dim3 grid(trace_grid(sc, n_host)), block(256);
     const uint32_t n32 = (uint32_t)n_host;
     // wave scheduling thresholds (refill, descend_min, leaf_min): measured optimum per kernel
+    const bool near_form = mode == RT_MODE_FAST_NEAR_F32;
+    if (near_form) mode = RT_MODE_FAST_F32;
     const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_wide;
-    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : 60;
-    const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 32 : 24);
-    const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 16 : 8);
+    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 58 : 60);
+    const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 36 : 24);
+    const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 12 : 8);
     switch (mode) {
     case RT_MODE_FAST_F32:
         if (sc.d_wide) {
             const int rb = t_refill;
             if (d_counters) {
-                hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                if (near_form) hipLaunchKernelGGL((k_trace_fast<true, 16, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                else hipLaunchKernelGGL((k_trace_fast<true, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+            } else if (near_form) {
+                switch (sc.tune_stack) {
+                case 12: hipLaunchKernelGGL((k_trace_fast<false, 12, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 16: hipLaunchKernelGGL((k_trace_fast<false, 16, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 24: hipLaunchKernelGGL((k_trace_fast<false, 24, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 8, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                }
             } else {
                 switch (sc.tune_stack) {
                 case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
@@ -1562,12 +1594,28 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
     if (sample_begin < 0 || sample_count < 0) return fail(RT_ERR_INVALID, "bad sample range");
     if (d_rgba && (int64_t)sample_begin + (int64_t)sample_count < 1)
         return fail(RT_ERR_INVALID, "an image of zero samples cannot be resolved");
-    if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64)
+    if (mode != RT_MODE_STRICT_F32 && mode != RT_MODE_FAST_F32 && mode != RT_MODE_FP64 && mode != RT_MODE_FAST_NEAR_F32)
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
     const rt_pass &pass = passes[0];
     PassParams pp;
     rt_status st = prepare_pass(sc.light, pass, pp);
     if (st != RT_OK) return st;
+    // The ordered traversal takes its near-origin form when every camera ray of the frame
+    // starts inside the scene's near region (camera.go:115-121: a ray starts on the
+    // projection plane; the frame's four corners bound all of them, the map is affine);
+    // shadow and bounce rays start on the scene's surfaces, inside that region by
+    // construction.  Tiles of one call share camera and frame.
+    if (mode == RT_MODE_FAST_F32 || mode == RT_MODE_FAST_NEAR_F32) {
+        bool inside = sc.d_wide != nullptr;
+        for (int corner = 0; corner < 4 && inside; ++corner) {
+            const float lx = pp.top_left[0] + pp.steps[0] * (float)((corner & 1) ? pass.total_width : 0);
+            const float ly = pp.top_left[1] - pp.steps[1] * (float)((corner & 2) ? pass.total_height : 0);
+            const v3 o = transform_coordinate(v3{lx, ly, -pp.ppd}, pp.cam_transform);
+            const float c[3] = {o.x, o.y, o.z};
+            for (int a = 0; a < 3; ++a) inside = inside && c[a] >= sc.near_lo[a] && c[a] <= sc.near_hi[a];
+        }
+        mode = inside ? RT_MODE_FAST_NEAR_F32 : RT_MODE_FAST_F32;
+    }
     pp.incremental = incremental ? 1 : 0;
     size_t pixels = (size_t)pass.width * (size_t)pass.height;
     std::vector<TileDesc> tiles;

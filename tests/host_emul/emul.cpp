@@ -52,8 +52,9 @@ void emul_trace(const float *nodes, int32_t n_nodes, const float *tris, int32_t 
     }
 }
 
+// near_form != 0: the near-origin form of the step (RT_MODE_FAST_NEAR_F32)
 void emul_trace_fast(const float *wide, uint32_t fast_root, const float *tris, int32_t n_tris,
-                     const EmulRay *rays, int64_t n, EmulHit *hits, uint64_t *counters) {
+                     const EmulRay *rays, int64_t n, EmulHit *hits, uint64_t *counters, int near_form) {
     DevScene s{};
     s.wide = reinterpret_cast<const f4 *>(wide);
     s.fast_root = fast_root;
@@ -66,7 +67,8 @@ void emul_trace_fast(const float *wide, uint32_t fast_root, const float *tris, i
         Ray<float> ray;
         ray_init(ray, r.o[0], r.o[1], r.o[2], r.dir[0], r.dir[1], r.dir[2]);
         Hit<float> h{r.tmax, 0, 0, -1};
-        traverse_ordered<true>(s, ray, h, &c);
+        if (near_form) traverse_ordered<true, true>(s, ray, h, &c);
+        else traverse_ordered<true, false>(s, ray, h, &c);
         hits[i] = EmulHit{h.pos, h.t, h.u, h.v};
         tot[0] += c.nodes_visited; tot[1] += c.box_tests; tot[2] += c.tris_fetched; tot[3] += c.tris_tested;
     }

@@ -177,7 +177,7 @@ def test_default_sample_table_is_low_discrepancy(product_lib):
     assert not np.array_equal(t, api.default_sample_table(4096, 6))
 
 
-def emul_trace_fast(emul, bvh, rays):
+def emul_trace_fast(emul, bvh, rays, near=False):
     rec, root = bvh.flatten_ordered()
     _, tris, _ = bvh.flatten()
     hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
@@ -185,21 +185,23 @@ def emul_trace_fast(emul, bvh, rays):
     emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
                          tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
                          rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
-                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), C.c_int(int(near)))
     return hits, cnt
 
 
+@pytest.mark.parametrize("near", [False, True])
 @pytest.mark.parametrize("n,leaf,depth", [(1, 6, 16), (34, 1, 8), (5000, 6, 24), (400, 200, 4),
                                           (3000, 1, 12)])
-def test_ordered_traversal_finds_the_same_hits(product_lib, oracle, emul, n, leaf, depth):
+def test_ordered_traversal_finds_the_same_hits(product_lib, oracle, emul, n, leaf, depth, near):
     """Fast mode: same closest hit as the reference order on generic rays (no
-    exact ties in a random soup), with far less work."""
+    exact ties in a random soup), with far less work; in both forms of the step
+    (the rays start inside the near region: the soup's box grown by its diagonal)."""
     sc = scenes.soup(n, seed=777 + n)
     bvh = api.Bvh.build(product_mesh(sc), True, leaf, depth)
     osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
     rays = random_rays(8000, seed=5)
     rays["tmax"][::4] = np.float32(1.5)
-    hits, cnt = emul_trace_fast(emul, bvh, rays)
+    hits, cnt = emul_trace_fast(emul, bvh, rays, near)
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax, counters=True)
     diff = hits["tri_pos"] != ref["tri"]
@@ -289,18 +291,28 @@ def test_ordered_records_layout(product_lib):
     step = rec[:, 3:6]
     assert np.isfinite(step).all() and (step > 0).all()
     lo, hi = _decode_wide(rec)
+    ext = e["bmax"][0].astype(np.float64) - e["bmin"][0]
+    margin = (ext + np.linalg.norm(ext)) * 2.0 ** -23          # rt_core.h: kNearOriginDiagonals = 1
     v = sc["verts"].reshape(-1, 3, 3)[e["order"]]
     for r, c in zip(*np.nonzero(leaf)):
         s0, n0 = int(refs[r, c] & 0xFFFFFF), int((refs[r, c] >> 24) & 0x7F)
         tri = v[s0:s0 + n0].reshape(-1, 3)
         assert (lo[r, c] <= tri.min(axis=0)).all() and (hi[r, c] >= tri.max(axis=0)).all()
-        # ... and are not looser than one step per side
-        assert (tri.min(axis=0) - lo[r, c] <= step[r] * 1.001).all()
-        assert (hi[r, c] - tri.max(axis=0) <= step[r] * 1.001).all()
+        # ... with the margin the near-origin form of the step needs (2^-23 of the farthest a
+        # qualifying ray origin can be from a frame origin, per axis) ...
+        # (in exact arithmetic, offset * step + origin before any rounding: what the near-origin
+        # form adds the ray-relative frame origin to)
+        x_lo = lo_q[r, c] * step[r].astype(np.float64) + rec[r, 0:3].astype(np.float64)
+        x_hi = hi_q[r, c] * step[r].astype(np.float64) + rec[r, 0:3].astype(np.float64)
+        assert (tri.min(axis=0).astype(np.float64) - x_lo >= margin * 0.999).all()
+        assert (x_hi - tri.max(axis=0).astype(np.float64) >= margin * 0.999).all()
+        # ... and are not looser than one step plus that margin per side
+        assert (tri.min(axis=0) - lo[r, c] <= step[r] * 1.001 + margin).all()
+        assert (hi[r, c] - tri.max(axis=0) <= step[r] * 1.001 + margin).all()
     # the root record's children cover the root box of the reference tree
     used0 = ~unused[0]
     assert (lo[0][used0].min(axis=0) <= e["bmin"][0]).all() and (hi[0][used0].max(axis=0) >= e["bmax"][0]).all()
-    assert np.array_equal(rec[0, 0:3], e["bmin"][0])
+    assert (rec[0, 0:3] <= e["bmin"][0]).all() and (e["bmin"][0] - rec[0, 0:3] <= margin * 1.01 + 1e-7).all()
     # a tree that is one big leaf becomes a tree of small leaves
     big = api.Bvh.build(product_mesh(scenes.soup(500, seed=3)), False, 6, 16)
     rec, root = big.flatten_ordered()

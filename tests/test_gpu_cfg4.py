@@ -107,6 +107,10 @@ def test_cfg4_incoherent_rays_strict_vs_fast(room_10m, oracle):
     assert counts["differing"] <= 60, counts
     same = a["tri_pos"] == b["tri_pos"]
     assert np.array_equal(a["t"][same].view(np.uint32), b["t"][same].view(np.uint32))
+    c, _ = scene.trace_rays(rays, mode=api.MODE_FAST_NEAR_F32)      # the origins lie inside the room
+    counts = classify_fast_differences(oracle, sc["verts"], order, rays, c, a["tri_pos"], a["t"])
+    record_parity_counts("config4_scene_2M_incoherent_rays_fast_near_form_vs_strict", counts)
+    assert counts["differing"] <= 60, counts
     # geometric check without the oracle: (t, u, v) reproduces the hit point inside the triangle
     v = sc["verts"].reshape(-1, 3, 3)
     ok = b["tri_pos"] >= 0

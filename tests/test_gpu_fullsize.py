@@ -54,6 +54,16 @@ def test_config1_every_primary_ray_bit_exact(product_lib, oracle, gpu_device):
     same = fast["tri_pos"] == hits["tri_pos"]
     assert counts["differing"] <= 20, counts
     assert np.array_equal(fast["t"][same].view(np.uint32), hits["t"][same].view(np.uint32))
+    # the near-origin form of the ordered step (the camera lies within one scene diagonal of the soup)
+    info = scene.info()
+    assert all(info["near_lo"][a] <= rays["origin"][:, a].min() and rays["origin"][:, a].max() <= info["near_hi"][a]
+               for a in range(3))
+    near, _ = scene.trace_rays(rays, mode=api.MODE_FAST_NEAR_F32)
+    counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, near, ref["tri"], ref["t"])
+    record_parity_counts("config1_fast_near_form_vs_oracle", counts)
+    same = near["tri_pos"] == hits["tri_pos"]
+    assert counts["differing"] <= 20, counts
+    assert np.array_equal(near["t"][same].view(np.uint32), hits["t"][same].view(np.uint32))
     # float64 validation mode against the float32 reference: the counted edge-grazing set
     h64, _ = scene.trace_rays(rays, mode=api.MODE_FP64)
     r64 = osc.trace_rays(r6, tmax, mode=1)
@@ -184,4 +194,8 @@ def test_room_1m_hits_lie_in_their_triangles(room_1m, oracle):
     b, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
     counts = classify_fast_differences(oracle, sc["verts"], order, rays, b, a["tri_pos"], a["t"])
     record_parity_counts("config2_scene_2M_incoherent_rays_fast_vs_strict", counts)
+    assert counts["differing"] <= 40, counts
+    c, _ = scene.trace_rays(rays, mode=api.MODE_FAST_NEAR_F32)      # the origins lie inside the room
+    counts = classify_fast_differences(oracle, sc["verts"], order, rays, c, a["tri_pos"], a["t"])
+    record_parity_counts("config2_scene_2M_incoherent_rays_fast_near_form_vs_strict", counts)
     assert counts["differing"] <= 40, counts

@@ -172,7 +172,11 @@ def test_scene_info_and_errors(soup20k, gpu_device):
 # form bit for bit; equal to the reference order except for a counted handful
 # of rays where the reference's own box pruning rejects a triangle it accepts
 # ---------------------------------------------------------------------------
-def _emul_fast(emul, bvh, rays):
+# the two forms of the ordered step: (mode, near-origin form of the lane-serial code)
+FAST_FORMS = [(api.MODE_FAST_F32, False), (api.MODE_FAST_NEAR_F32, True)]
+
+
+def _emul_fast(emul, bvh, rays, near=False):
     import ctypes as C
     rec, root = bvh.flatten_ordered()
     _, tris, _ = bvh.flatten()
@@ -181,22 +185,23 @@ def _emul_fast(emul, bvh, rays):
     emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
                          tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
                          rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
-                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+                         hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), C.c_int(int(near)))
     return hits, cnt
 
 
-def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul, oracle):
+@pytest.mark.parametrize("mode,near", FAST_FORMS)
+def test_fast_mode_matches_cpu_form_and_reference(soup20k, emul, oracle, mode, near):
     sc, _, bvh, scene, osc = soup20k
-    rays = random_rays(300000, seed=9)
+    rays = random_rays(300000, seed=9)          # origins within 1.5 of the centre: inside the near region
     rays["tmax"][::7] = np.float32(0.9)
-    hits, st = scene.trace_rays(rays, mode=api.MODE_FAST_F32, counters=True)
-    cpu, cnt = _emul_fast(emul, bvh, rays)
+    hits, st = scene.trace_rays(rays, mode=mode, counters=True)
+    cpu, cnt = _emul_fast(emul, bvh, rays, near)
     assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
     assert [st["rays"], st["nodes_visited"], st["box_tests"], st["tris_fetched"], st["tris_tested"]] == cnt.tolist()
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax, counters=True)
     counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
-    record_parity_counts("soup20k_300k_incoherent_rays_fast_vs_oracle", counts)
+    record_parity_counts("soup20k_300k_incoherent_rays_fast_vs_oracle" + ("_near_form" if near else ""), counts)
     assert counts["differing"] <= 3, counts
     same = hits["tri_pos"] == ref["tri"]
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
@@ -228,7 +233,8 @@ def test_fast_mode_with_point_triangles(product_lib, emul, gpu_device):
     assert np.array_equal(hits["tri_pos"], strict["tri_pos"])
 
 
-def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
+@pytest.mark.parametrize("mode,near", FAST_FORMS)
+def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device, mode, near):
     """Rays along quad diagonals and box faces: exact t ties between the two
     triangles of a wall resolve to the earlier array position, as in the
     reference order."""
@@ -249,11 +255,11 @@ def test_fast_mode_on_axis_aligned_geometry(product_lib, oracle, gpu_device):
     rays = np.concatenate([api.make_rays(o, d),
                            api.make_rays(np.array(extra_o, np.float32), np.array(extra_d, np.float32)),
                            random_rays(100000, seed=2, extent=1.0)])
-    hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
+    hits, _ = scene.trace_rays(rays, mode=mode)
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax)
     counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
-    record_parity_counts("room6k_axis_aligned_fast_vs_oracle", counts)
+    record_parity_counts("room6k_axis_aligned_fast_vs_oracle" + ("_near_form" if near else ""), counts)
     assert counts["differing"] <= 1e-4 * len(rays), counts
     same = (hits["tri_pos"] == ref["tri"])
     assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
@@ -269,12 +275,13 @@ def test_fast_mode_deep_and_degenerate_trees(product_lib, oracle, gpu_device):
         scene = api.Scene(mesh, bvh, gpu_device)
         osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
         rays = random_rays(20000, seed=n, extent=1.0)
-        hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
         r6, tmax = rays6(rays)
         ref = osc.trace_rays(r6, tmax)
-        counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
-        assert counts["differing"] <= 2, counts
-        assert (hits["tri_pos"] >= 0).sum() > 0
+        for mode, _near in FAST_FORMS:
+            hits, _ = scene.trace_rays(rays, mode=mode)
+            counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"])
+            assert counts["differing"] <= 2, counts
+            assert (hits["tri_pos"] >= 0).sum() > 0
 
 
 @pytest.mark.parametrize("scale,offset", [(1.0e6, 0.0), (0.6, 0.0), (1.0, 4.0e4), (1.0e3, -7.0e6)])
@@ -294,27 +301,29 @@ def test_fast_mode_at_extreme_scales(product_lib, oracle, gpu_device, emul, scal
     rays["origin"] = (rays["origin"] * np.float32(scale) + np.float32(offset)).astype(np.float32)
     rays["dir"][::9, 0] = np.float32(1e-41)
     rays["dir"][4::9, 2] = np.float32(0.0)
-    hits, _ = scene.trace_rays(rays, mode=api.MODE_FAST_F32)
-    cpu, _ = _emul_fast(emul, bvh, rays)
-    assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
     r6, tmax = rays6(rays)
     ref = osc.trace_rays(r6, tmax)
-    counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"], ref["t"],
-                                       degenerate_ok=True)
-    record_parity_counts(f"soup6k_scale_{scale:g}_offset_{offset:g}_fast_vs_oracle", counts)
-    differ = hits["tri_pos"] != ref["tri"]
-    degenerate = np.zeros(len(rays), bool)
-    degenerate[::9] = True
-    degenerate[4::9] = True
-    assert int((differ & ~degenerate).sum()) <= 3
-    # A zero or denormal direction component gives an infinite inverse direction;
-    # where such a ray starts exactly on a box plane (common when the coordinates
-    # are coarse in float32) the product is NaN, which the reference's
-    # compare-and-assign slab (aabb.go:71-96) and the min/max slab of the ordered
-    # traversal treat differently: a small counted share of those rays.
-    assert int((differ & degenerate).sum()) <= max(3, int(0.002 * degenerate.sum()))
-    same = ~differ
-    assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
+    for mode, near in FAST_FORMS:          # the rays start inside the near region whatever the scale
+        hits, _ = scene.trace_rays(rays, mode=mode)
+        cpu, _ = _emul_fast(emul, bvh, rays, near)
+        assert np.array_equal(hits.view(np.uint32), cpu.view(np.uint32))
+        counts = classify_fast_differences(oracle, sc["verts"], bvh.export()["order"], rays, hits, ref["tri"],
+                                           ref["t"], degenerate_ok=True)
+        record_parity_counts(f"soup6k_scale_{scale:g}_offset_{offset:g}_fast_vs_oracle" + ("_near_form" if near else ""),
+                             counts)
+        differ = hits["tri_pos"] != ref["tri"]
+        degenerate = np.zeros(len(rays), bool)
+        degenerate[::9] = True
+        degenerate[4::9] = True
+        assert int((differ & ~degenerate).sum()) <= 3
+        # A zero or denormal direction component gives an infinite inverse direction;
+        # where such a ray starts exactly on a box plane (common when the coordinates
+        # are coarse in float32) the product is NaN, which the reference's
+        # compare-and-assign slab (aabb.go:71-96) and the min/max slab of the ordered
+        # traversal treat differently: a small counted share of those rays.
+        assert int((differ & degenerate).sum()) <= max(3, int(0.002 * degenerate.sum()))
+        same = ~differ
+        assert np.array_equal(hits["t"][same].view(np.uint32), ref["t"][same].view(np.uint32))
     # the scale must not make the scene invisible to the test
     assert (ref["tri"] >= 0).sum() > 100
 

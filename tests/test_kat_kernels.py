@@ -59,7 +59,9 @@ def _cube_tree_json(box):
                                    "Bounds": {"Bounds": [mn, mx]}, "StartIndex": s, "EndIndex": s,
                                    "SplitPlane": [0, 0, 0, 0]}
     return json.dumps({"Root": {
-        "Depth": 0, "Index": 0, "Bounds": {"Bounds": [[-2000, -2000, -2000], [2000, 2000, 2000]]},
+        # (the ordered view keeps its planes 2^-23 of the scene's extent + diagonal outside the boxes:
+        # 3e-4 for these root bounds, well inside the 1e-3 by which the "should miss" vector misses)
+        "Depth": 0, "Index": 0, "Bounds": {"Bounds": [[-2, -2, -2], [1001, 1001, 1001]]},
         "StartIndex": 0, "EndIndex": 1, "SplitPlane": [1, 0, 0, 500.0],
         "LeftChild": leaf(0, box["min"], box["max"], 1),
         "RightChild": leaf(1, [0.0, 0.0, 0.0], [0.125, 0.125, 0.125], 2)}})
@@ -80,12 +82,13 @@ def _emul(emul, bvh, rays, mode, counters=False):
     hits = np.zeros(rays.shape[0], api.HIT_DTYPE)
     cnt = np.zeros(5, np.uint64)
     _, tris, _ = bvh.flatten()
-    if mode == api.MODE_FAST_F32:
+    if mode in FAST_MODES:
         rec, root = bvh.flatten_ordered()
         emul.emul_trace_fast(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root),
                              tris.ctypes.data_as(C.c_void_p), C.c_int32(tris.shape[0]),
                              rays.ctypes.data_as(C.c_void_p), C.c_int64(rays.shape[0]),
-                             hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+                             hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                             C.c_int(int(mode == api.MODE_FAST_NEAR_F32)))
     else:
         nodes, _, _ = bvh.flatten()
         emul.emul_trace(nodes.ctypes.data_as(C.c_void_p), C.c_int32(nodes.shape[0]),
@@ -95,7 +98,8 @@ def _emul(emul, bvh, rays, mode, counters=False):
     return hits, int(cnt[3])
 
 
-MODES = [api.MODE_STRICT_F32, api.MODE_FP64, api.MODE_FAST_F32]
+FAST_MODES = (api.MODE_FAST_F32, api.MODE_FAST_NEAR_F32)     # both forms of the ordered step
+MODES = [api.MODE_STRICT_F32, api.MODE_FP64, api.MODE_FAST_F32, api.MODE_FAST_NEAR_F32]
 
 
 def _run_box_vectors(oracle, trace):
@@ -122,7 +126,7 @@ def _run_box_vectors(oracle, trace):
                     r2["tmax"] = tmax
                     hits, fetched = trace(mesh, bvh, r2, mode, counters=True)
                     assert int(hits[0]["tri_pos"]) == -1 and float(hits[0]["t"]) == float(tmax), mode
-                    if entered or mode != api.MODE_FAST_F32:
+                    if entered or mode not in FAST_MODES:
                         assert (fetched >= 1) == entered, (mode, float(tmax), fetched)
 
 
