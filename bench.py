@@ -288,6 +288,7 @@ class Workload:
         self.sc = scenes.room_mesh(wl["grid"], seed=wl.get("seed", 0x5EED0002), total=wl["tris"])
         sc = self.sc
         self.mesh = api.Mesh(sc["verts"], sc["material"], sc["group_index"], sc["kd"], sc["is_light"])
+        t_mesh = time.perf_counter()
         if world == 1:
             self.bvh = api.Bvh.build(self.mesh, True, wl["leaf"], wl["depth"])
         else:
@@ -312,8 +313,12 @@ class Workload:
             dist.barrier()
             if rank == 0 and os.path.exists(cache):
                 os.remove(cache)
+        t_bvh = time.perf_counter()
         self.scene = api.Scene(self.mesh, self.bvh, job.local_rank)
         self.setup_s = time.perf_counter() - t0
+        # where the set-up time goes: synthetic mesh, SAH build (or load of rank 0's tree), flatten + upload
+        self.setup_parts = {"mesh_s": round(t_mesh - t0, 2), "bvh_s": round(t_bvh - t_mesh, 2),
+                            "scene_s": round(time.perf_counter() - t_bvh, 2)}
         args = job.args
         if args.tune:
             self.scene.set_tuning(*[int(x) for x in args.tune.split(",")])
@@ -595,7 +600,7 @@ def extra_object(W, leg):
             "warmup": leg["warmup"], "rays_per_step": leg["rays_per_step"],
             "triangles": int(W.mesh.n_tris), "width": W.wl["width"], "height": W.wl["height"], "spp": leg["spp"],
             "paths_per_batch": leg["paths_per_batch"], "batch_halved_by_library": leg["batch_halved_by_library"],
-            "workspace_gb": leg["workspace_gb"], "setup_s": round(W.setup_s, 2),
+            "workspace_gb": leg["workspace_gb"], "setup_s": round(W.setup_s, 2), "setup_parts": W.setup_parts,
             "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                "rays_per_s_in_kernel", "kernel_ms_per_step",
                                                "kernel_launches_per_step", "kernel_avg_launch_ms", "nodes_per_ray",
@@ -635,7 +640,8 @@ def main():
                        "paths_per_batch_asked": leg["paths_per_batch_asked"],
                        "batch_halved_by_library": leg["batch_halved_by_library"],
                        "workspace_gb": leg["workspace_gb"],
-                       "rays_per_step": leg["rays_per_step"], "setup_s": round(W.setup_s, 2)},
+                       "rays_per_step": leg["rays_per_step"], "setup_s": round(W.setup_s, 2),
+                       "setup_parts": W.setup_parts},
             "roofline": roof,
         }
         if leg["per_rank"]:

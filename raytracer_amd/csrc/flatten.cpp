@@ -89,12 +89,28 @@ struct WideBuilder {
     int32_t best_cut(int32_t start, int32_t count) const {
         float cost[kCutSearch + 1][kCutSearch + 1];   // [first][length]
         int32_t cut[kCutSearch + 1][kCutSearch + 1];
+        // box area of every sub-range [i, i + len): each triangle's own box once, then
+        // unions grown one triangle at a time (min and max do not depend on the order)
+        float area_of[kCutSearch + 1][kCutSearch + 1];
+        {
+            float tmn[kCutSearch][3], tmx[kCutSearch][3];
+            for (int32_t i = 0; i < count; ++i) range_box(start + i, 1, tmn[i], tmx[i]);
+            for (int32_t i = 0; i < count; ++i) {
+                float mn[3] = {tmn[i][0], tmn[i][1], tmn[i][2]}, mx[3] = {tmx[i][0], tmx[i][1], tmx[i][2]};
+                for (int32_t len = 1; i + len <= count; ++len) {
+                    const int32_t j = i + len - 1;
+                    for (int k = 0; k < 3; ++k) {
+                        if (tmn[j][k] < mn[k]) mn[k] = tmn[j][k];
+                        if (tmx[j][k] > mx[k]) mx[k] = tmx[j][k];
+                    }
+                    const float d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
+                    area_of[i][len] = d0 * d1 + d0 * d2 + d1 * d2;
+                }
+            }
+        }
         for (int32_t len = 1; len <= count; ++len)
             for (int32_t i = 0; i + len <= count; ++i) {
-                float mn[3], mx[3];
-                range_box(start + i, len, mn, mx);
-                const float d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
-                const float a = d0 * d1 + d0 * d2 + d1 * d2;
+                const float a = area_of[i][len];
                 const float whole = a * kLeafCost * (float)((len + 1) / 2);
                 cut[i][len] = 0;
                 cost[i][len] = whole;
@@ -399,14 +415,32 @@ rt_status flatten(const rt_mesh &mesh, const Bvh &bvh, FlatScene &out) {
     for (int32_t pos = 0; pos < mesh.n_tris; ++pos) {
         const int32_t id = bvh.order[(size_t)pos];
         if (id < 0 || id >= mesh.n_tris) return fail(RT_ERR_INVALID, "BVH order entry out of range");
-        TriRecord rec;
-        make_tri_record(mesh.verts + 9 * (size_t)id, rec);
-        tris[3 * (size_t)pos] = f4{rec.normal[0], rec.normal[1], rec.normal[2], rec.v0[0]};
-        tris[3 * (size_t)pos + 1] = f4{rec.v0[1], rec.v0[2], rec.e0[0], rec.e0[1]};
-        tris[3 * (size_t)pos + 2] = f4{rec.e0[2], rec.v0v2[0], rec.v0v2[1], rec.v0v2[2]};
-        const int32_t mat = mesh.material ? mesh.material[id] : 0;
-        out.tri_mat[(size_t)pos] = mat | (mesh.is_light[mat] ? rtc::kLightBit : 0);
-        if (mesh.texcoords) std::memcpy(&out.tri_uv[6 * (size_t)pos], mesh.texcoords + 6 * (size_t)id, 24);
+    }
+    // the per-triangle records are independent of each other: large meshes fill them in
+    // slices on several threads
+    auto fill = [&](int32_t first, int32_t last) {
+        for (int32_t pos = first; pos < last; ++pos) {
+            const int32_t id = bvh.order[(size_t)pos];
+            TriRecord rec;
+            make_tri_record(mesh.verts + 9 * (size_t)id, rec);
+            tris[3 * (size_t)pos] = f4{rec.normal[0], rec.normal[1], rec.normal[2], rec.v0[0]};
+            tris[3 * (size_t)pos + 1] = f4{rec.v0[1], rec.v0[2], rec.e0[0], rec.e0[1]};
+            tris[3 * (size_t)pos + 2] = f4{rec.e0[2], rec.v0v2[0], rec.v0v2[1], rec.v0v2[2]};
+            const int32_t mat = mesh.material ? mesh.material[id] : 0;
+            out.tri_mat[(size_t)pos] = mat | (mesh.is_light[mat] ? rtc::kLightBit : 0);
+            if (mesh.texcoords) std::memcpy(&out.tri_uv[6 * (size_t)pos], mesh.texcoords + 6 * (size_t)id, 24);
+        }
+    };
+    if (mesh.n_tris > 200000) {
+        const int32_t slices = 8;
+        std::vector<std::function<void()>> jobs;
+        for (int32_t k = 0; k < slices; ++k) {
+            const int32_t first = (int32_t)((int64_t)mesh.n_tris * k / slices), last = (int32_t)((int64_t)mesh.n_tris * (k + 1) / slices);
+            jobs.push_back([&fill, first, last] { fill(first, last); });
+        }
+        run_together(jobs);
+    } else {
+        fill(0, mesh.n_tris);
     }
     build_wide(mesh, bvh, skip, out);
     return RT_OK;
