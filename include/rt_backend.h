@@ -60,6 +60,11 @@ rt_status rtb_incremental_render(rtb_context *ctx, char **result_json, size_t *l
 
 /* context.Rays (process/trace.go:122; reset when RenderKey changes, main.go:107-110) */
 uint64_t rtb_rays(const rtb_context *ctx);
+/* At how many separate moments the last render() call sent its intermediate "trace"
+ * progress updates (utility.go:13-32, main.go:120-154): 1 when they all went out
+ * after the tile was done (tiles below 2^22 camera samples), more when a large tile
+ * was traced range by range and reported while it rendered; 0 without a callback. */
+uint32_t rtb_progress_deliveries(const rtb_context *ctx);
 /* number of triangles after initialize (0 before) */
 int32_t rtb_triangle_count(const rtb_context *ctx);
 /* Raw RGBA8 bytes of the last render / incrementalRender result (width*height*4),

@@ -33,6 +33,7 @@ _SIGNATURES = {
                                                       C.POINTER(C.c_size_t)]),
     "rtb_incremental_render": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "rtb_rays": (C.c_uint64, [vp]),
+    "rtb_progress_deliveries": (C.c_uint32, [vp]),
     "rtb_triangle_count": (C.c_int32, [vp]),
     "rtb_last_image": (C.c_size_t, [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
@@ -126,6 +127,11 @@ class Backend:
     @property
     def rays(self):
         return int(_lib().rtb_rays(self._h))
+
+    @property
+    def progress_deliveries(self):
+        """Separate moments at which the last render() sent its trace updates."""
+        return int(_lib().rtb_progress_deliveries(self._h))
 
     @property
     def triangle_count(self):

@@ -47,6 +47,7 @@ struct rtb_context {
     rt::Scene *scene = nullptr;            // device copy, made at the first render
     uint64_t rays = 0;
     int32_t active_render_key = -1;
+    uint32_t progress_deliveries = 0;      // separate moments at which the last render sent trace updates
 
     // incremental render state (main.go:190-194)
     bool inc_ready = false;
@@ -405,9 +406,13 @@ rt_status rtb_render(rtb_context *ctx, const char *pass_json, char **result_json
     }
     ctx->last_image.assign((size_t)pass.width * (size_t)pass.height * 4, 0);
     // main.go:117-122: an update whenever the running sample index passes
-    // updateIndex + updateInterval.  The tile is traced as a whole here, so the
-    // events go out together once it is done, with the values the reference's
-    // counter has at those sample indices.
+    // updateIndex + updateInterval, each with the value the reference's ray counter has
+    // at that sample index.  A small tile is traced as a whole and its events go out
+    // together once it is done (a preset tile takes a millisecond); a large one (from
+    // kProgressiveSamples camera samples) is traced in ten pixel ranges and the events
+    // whose sample indices a range completes go out as soon as it is done, so that a
+    // caller sees progress while a long pass renders, as with the reference.
+    constexpr int64_t kProgressiveSamples = 1 << 22;
     rt::ProgressBins bins;
     const int64_t ray_count = (int64_t)pass.width * (int64_t)pass.height * (int64_t)pass.camera.rays_per_pixel;
     const int64_t interval = (int64_t)((float)ray_count / 10.0f);
@@ -418,23 +423,36 @@ rt_status rtb_render(rtb_context *ctx, const char *pass_json, char **result_json
         if (events > rt::kProgressBins - 1) events = rt::kProgressBins - 1;
         bins.n_bins = (int32_t)events + 1;
     }
+    const uint64_t rays_before = ctx->rays;
+    int32_t sent = 0;                      // events 1..sent have gone out
+    ctx->progress_deliveries = 0;
+    auto send_up_to = [&](int32_t complete) {
+        // event k reports the rays of the camera samples below k * step: bins 0..k-1
+        if (complete > bins.n_bins - 1) complete = bins.n_bins - 1;
+        if (complete <= sent) return;
+        uint64_t running = 0;
+        for (int32_t k = 1; k <= complete; ++k) {
+            running += bins.rays[k - 1];
+            if (k <= sent) continue;
+            ctx->rays = rays_before + running;
+            send_progress(ctx, (float)((int64_t)k * (interval + 1)) / (float)ray_count, "trace", pass.task_id);
+        }
+        ctx->rays = rays_before;
+        sent = complete;
+        ctx->progress_deliveries++;
+    };
+    if (want_progress && ray_count >= kProgressiveSamples) {
+        bins.chunks = 10;
+        bins.on_range = send_up_to;
+    }
     rt_stats stats;
     st = rt::render_tile_host(*ctx->scene, pass, ctx->mode, nullptr, ctx->last_image.data(), &stats,
                               want_progress ? &bins : nullptr);
     if (st != RT_OK) return error_result(st, result_json_out, len);
     ctx->last_w = pass.width;
     ctx->last_h = pass.height;
-    if (want_progress) {
-        const uint64_t before = ctx->rays;
-        uint64_t running = 0;
-        for (int32_t k = 1; k < bins.n_bins; ++k) {
-            running += bins.rays[k - 1];
-            ctx->rays = before + running;
-            send_progress(ctx, (float)((int64_t)k * (interval + 1)) / (float)ray_count, "trace", pass.task_id);
-        }
-        ctx->rays = before;
-    }
-    ctx->rays += stats.rays;
+    if (want_progress) send_up_to(bins.n_bins - 1);      // whatever has not gone out yet
+    ctx->rays = rays_before + stats.rays;
     send_progress(ctx, 1.0f, "trace", pass.task_id);
     send_progress(ctx, 0.0f, "output", pass.task_id);
     *result_json_out = dup_string(result_json(0, "", ctx->last_image.data(), pass.width, pass.height), len);
@@ -523,6 +541,7 @@ rt_status rtb_incremental_render(rtb_context *ctx, char **result_json_out, size_
 }
 
 uint64_t rtb_rays(const rtb_context *ctx) { return ctx ? ctx->rays : 0; }
+uint32_t rtb_progress_deliveries(const rtb_context *ctx) { return ctx ? ctx->progress_deliveries : 0; }
 int32_t rtb_triangle_count(const rtb_context *ctx) { return (ctx && ctx->initialized) ? ctx->mesh.n_tris : 0; }
 
 size_t rtb_last_image(const rtb_context *ctx, const uint8_t **pixels, int32_t *width, int32_t *height) {

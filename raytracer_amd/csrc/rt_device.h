@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -71,6 +72,12 @@ struct ProgressBins {
     uint32_t step = 1;                     // updateInterval + 1
     int32_t n_bins = 1;                    // bins in use (at most kProgressBins)
     unsigned long long rays[kProgressBins] = {};
+    // chunks > 1: the tile is traced in that many pixel ranges, one after the other, and
+    // after each but the last `on_range` is called with the number of bins that are
+    // complete by then (`rays` holds their sums): the caller can report progress WHILE
+    // the tile renders, as the reference does.  Results do not depend on the batch shape.
+    int32_t chunks = 1;
+    std::function<void(int32_t bins_complete)> on_range;
 };
 
 struct Scene {

@@ -1670,6 +1670,10 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
     if (max_paths * Lq > (size_t)0x7fffffff)
         return fail(RT_ERR_INVALID, "LightSampleRays too large: a ray queue would exceed 2^31-1 rays");
     size_t n_pix = pixels < max_paths ? pixels : max_paths;
+    if (progress && progress->chunks > 1) {
+        const size_t range = (pixels + (size_t)progress->chunks - 1) / (size_t)progress->chunks;
+        if (range >= 1 && range < n_pix) n_pix = range;
+    }
     size_t n_samp = max_paths / n_pix;
     if (n_samp < 1) n_samp = 1;
     if (n_samp > (size_t)sample_count) n_samp = (size_t)(sample_count > 0 ? sample_count : 1);
@@ -1776,6 +1780,17 @@ static rt_status render_core(Scene &sc, const rt_pass *passes, int32_t n_passes,
                 hipLaunchKernelGGL(k_progress_bins, grid, block, 0, stream, pp, b, w.path_rays, progress->step,
                                    progress->n_bins, w.progress_bins);
             HIP_TRY(hipGetLastError());
+        }
+        // a pixel range is done: report the progress bins that are complete by now (the camera
+        // samples of pixel i have the indices i * spp .. i * spp + spp - 1, main.go:132-152)
+        if (progress && progress->on_range && pix0 + np < pixels) {
+            HIP_TRY(hipMemcpyAsync(progress->rays, w.progress_bins, kProgressBins * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            const unsigned long long done = (unsigned long long)(pix0 + np) * (unsigned long long)sample_count;
+            unsigned long long complete = done / progress->step;
+            if (complete > (unsigned long long)progress->n_bins) complete = (unsigned long long)progress->n_bins;
+            progress->on_range((int32_t)complete);
         }
     }
     if (d_rgba) {

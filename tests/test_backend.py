@@ -298,3 +298,45 @@ def test_textured_material(product_lib, oracle, gpu_device):
     assert {0, 1, 2} <= set(np.unique(dominant[lit]).tolist())
     black = (~lit).mean()
     assert black < 0.1
+
+
+@pytest.mark.gpu
+def test_progress_events_arrive_while_a_large_tile_renders(product_lib, oracle, gpu_device):
+    """A tile of 2^22 camera samples or more (512x512 at 16 spp here) is traced in
+    ten pixel ranges and the trace updates whose sample indices a range completes
+    go out as soon as that range is done (the reference reports while it traces,
+    main.go:120-154).  The documents are the same as for a tile traced as a
+    whole: progress values and running ray counts equal the oracle's, the image
+    equals the oracle's tile."""
+    events = []
+    b = backend.Backend(device=gpu_device, progressUpdate=events.append)
+    b.initialize(_context_json())
+    b.loadBVH(b.buildBVH())
+    sc = cornell()
+    bvh = api.Bvh.build(product_mesh(sc), True, 6, 16)
+    osc = oracle_scene(oracle, sc, bvh_export=bvh.export())
+    osc.set_sample_tables(api.default_sample_table(12345, 0xC0FFEE01),
+                          api.default_sample_table(100001, 0xC0FFEE02))
+    cam = {"x": PRESET["x"], "y": PRESET["y"], "z": PRESET["z"]}
+    d = scenes.make_pass_dict(512, 512, cam, spp=16, bounces=1, light_samples=1, gamma=PRESET["gamma"],
+                              intensity=PRESET["lightIntensity"], seed=5, task_id=3)
+    assert d["Width"] * d["Height"] * 16 >= 1 << 22
+    doc = json.loads(b.render(json.dumps(d)))
+    assert doc["exitCode"] == 0
+    assert b.progress_deliveries >= 5, b.progress_deliveries        # not all at the end
+    want = oracle.render_progress(osc, oracle.pass_from_dict(d))
+    got = [json.loads(e) for e in events]
+    trace = [e for e in got if e["event"] == "trace"]
+    assert len(trace) == len(want) == 11
+    for e, (progress, rays) in zip(trace, want):
+        assert np.float32(e["progress"]) == np.float32(progress), (e, progress)
+        assert e["rays"] == rays, (e, rays)
+    assert b.rays == want[-1][1]
+    ref = osc.render_tile(oracle.pass_from_dict(d))
+    assert np.array_equal(backend.decode_image(doc), ref["rgba"])
+    # a small tile still reports once, after it is done
+    del events[:]
+    small = _tasks(spp=2)[0]
+    small["RenderKey"] = 9
+    assert json.loads(b.render(json.dumps(small)))["exitCode"] == 0
+    assert b.progress_deliveries == 1
