@@ -83,12 +83,15 @@ struct DevScene {
     //   [9..11] upper planes x, y, z, likewise
     //   [12..15] child refs: interior -> record index; leaf -> kLeafBit | count << 24
     //            | first triangle; unused slot -> kLeafBit (count 0)
+    // The kWideTopRecords records with the largest frames (a top of the tree) come
+    // first, largest first; the rest follow in depth-first order.
     // A plane decodes as fma(offset, step, origin); decoded boxes contain the
     // binary tree's boxes (lower planes rounded down, upper planes up) with a
     // small margin to spare (flatten.cpp: margin) for the near-origin form.
     const f4 *wide;
     uint32_t fast_root;         // ref of the root (a record index, or a leaf ref)
     int32_t fast_ok;            // 0: tree does not fit the fast encoding
+    int32_t n_wide;             // records in `wide`
     const double *cam_tab;      // n_cam * 2
     const double *light_tab;    // n_light * 2
     int32_t n_nodes, n_tris, n_cam, n_light;
@@ -100,6 +103,7 @@ constexpr uint32_t kRefDone = 0xFFFFFFFFu;   // empty-stack marker (count 127, s
 constexpr int32_t kFastSplitLeaf = 2;   // ordered view: leaf ranges up to this size are never cut (one leaf step tests two triangles)
 constexpr int32_t kFastMaxLeaf = 4;     // ordered view: larger leaf ranges are always cut; between the two the builder weighs the cut
 constexpr int32_t kWideFloats = 16;     // one ordered-traversal record: frame + 4 quantised child boxes + 4 refs = 64 bytes
+constexpr int32_t kWideTopRecords = 1024;   // ordered view: this many records with the largest frames lead the array (flatten.cpp: top_records_first)
 constexpr int32_t kFastStackEntries = 96;   // per-ray stack of the ordered traversal
 constexpr int32_t kFastMaxTris = (1 << 24) - 2;
 // Ordered traversal: a child box or stack entry is still entered when its entry

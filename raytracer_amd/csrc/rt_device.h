@@ -92,6 +92,7 @@ struct Scene {
     int32_t n_top = 0;
     rtc::f4 *d_wide = nullptr;        // ordered-traversal records (fast mode), may be null
     uint32_t fast_root = 0;
+    int32_t n_wide = 0;               // records in d_wide
     uint64_t wide_bytes = 0;
     float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};   // origin region of the near-origin ordered form
     rtc::f4 *d_tri_shade = nullptr;   // per triangle (normal, material word)

@@ -163,6 +163,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         for (int i = threadIdx.x; i < 2 * s.n_top; i += blockDim.x) top[i] = s.linked[i];
         __syncthreads();
     }
+    const uint32_t top_base = (uint32_t)(uintptr_t)top;   // a generic LDS address carries the LDS offset in its low half
     const uint32_t n = n_dev ? *n_dev : n_host;
     int32_t idx = -1;            // ray owned by this lane, -1 = idle
     RayFeed feed;
@@ -218,24 +219,38 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             if (!walking) continue;
             f4 lo, hi;
             if (TOP) {
+                // Lanes standing on a node of the LDS table read it from there, the others
+                // from memory, into the SAME registers, and one wait covers both: the two
+                // groups of lanes are disjoint, and a load writes only the lanes that issued
+                // it.  (Written as two C++ branches, the second waits for the first one's
+                // data before it issues, and the record is moved between registers.)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f wlo, whi;
+                asm volatile("" : "=v"(wlo), "=v"(whi));
                 if (node < s.n_top) {
-                    lo = top[2 * node];
-                    hi = top[2 * node + 1];
+                    const uint32_t at = top_base + ((uint32_t)node << 5);
+                    asm volatile("ds_read_b128 %0, %2\n\t"
+                                 "ds_read_b128 %1, %2 offset:16"
+                                 : "+v"(wlo), "+v"(whi) : "v"(at));
                 } else {
                     // 32-bit byte offset beside the scalar base (a linked view has fewer than 2^25 nodes)
-                    const f4 *q = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.linked) + ((uint32_t)node << 5));
-                    lo = q[0];
-                    hi = q[1];
+                    const uint32_t at = (uint32_t)node << 5;
+                    asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
+                                 "global_load_dwordx4 %1, %2, %3 offset:16"
+                                 : "+v"(wlo), "+v"(whi) : "v"(at), "s"(s.linked));
                 }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wlo), "+v"(whi));
+                lo = f4{wlo.x, wlo.y, wlo.z, wlo.w};
+                hi = f4{whi.x, whi.y, whi.z, whi.w};
             } else {
                 lo = s.nodes[2 * node];
                 hi = s.nodes[2 * node + 1];
+                // keep the record two 16-byte loads: left alone the compiler splits it into
+                // four 8-byte ones around the root test below, and the kernel is bound by the
+                // number of per-lane loads
+                asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(lo.w));
+                asm volatile("" : "+v"(hi.x), "+v"(hi.y), "+v"(hi.z), "+v"(hi.w));
             }
-            // keep the record two 16-byte loads: left alone the compiler splits it into
-            // four 8-byte ones around the root test below, and the kernel is bound by the
-            // number of per-lane loads
-            asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(lo.w));
-            asm volatile("" : "+v"(hi.x), "+v"(hi.y), "+v"(hi.z), "+v"(hi.w));
             const int32_t a = f2i(lo.w), b = f2i(hi.w);
             bool pass = true;
             if (node != 0) {
@@ -341,6 +356,11 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
 // would accept.
 // ---------------------------------------------------------------------------
 constexpr int kStackTotal = kFastStackEntries;
+// Records of the top of the tree that every block of the default ordered kernel
+// keeps in LDS (k_trace_fast: kTop): with the 8-entry stack, 16 KB + 80 x 80
+// bytes per block, seven blocks fill a CU's 160 KB -- the occupancy the kernel
+// has without the table.  Larger tables at lower occupancy measured slower.
+constexpr int kFastTopRecords = 80;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // The three plane pairs (near, far) of one child box, from plane offsets to slab
@@ -382,27 +402,47 @@ __device__ __forceinline__ void slab_planes_near(f2 &tx, f2 &ty, f2 &tz, f2 d_xy
         : "v"(d_xy), "v"(d_zsx), "v"(f_syz), "v"(r_ozix), "v"(r_iyz));
 }
 
-template <bool COUNT, int kStackLds, bool NEAR = false>
+template <bool COUNT, int kStackLds, bool NEAR = false, int kTop = 0>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
              unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
     constexpr int kStackSpill = kStackTotal - kStackLds;
-    __shared__ uint2 lds_stack[4 * kStackLds * 64];
+    constexpr int kBlock = 256;
+    __shared__ uint2 lds_stack[kBlock * kStackLds];
     // Values that no descent step reads -- the hit's u and v, the ray's index and
     // its direction (the descent uses the inverse direction) -- live in LDS,
-    // [value][thread]: the descent step is what sets the register count, and
-    // with it how many waves a SIMD holds.
-    __shared__ float park[6 * 256];
-    float *my_park = park + threadIdx.x;
+    // [value][thread], when that lets a SIMD hold one more wave (the descent step
+    // sets the register count).  With the record table below the LDS is what limits
+    // the waves, seven per SIMD either way, and the values stay in registers.
+    constexpr bool kParkRegs = kTop > 0;
+    __shared__ float park[kParkRegs ? 1 : 6 * kBlock];
+    float *my_park = park + (kParkRegs ? 0 : threadIdx.x);
+    float park_reg[6] = {0, 0, 0, 0, 0, 0};
+#define RT_PARK_SET(k, v) do { if (kParkRegs) park_reg[k] = (v); else my_park[(k) * kBlock] = (v); } while (0)
+#define RT_PARK_GET(k) (kParkRegs ? park_reg[k] : my_park[(k) * kBlock])
+    // The first kTop records of the array -- those with the largest frames, a top
+    // of the tree (flatten.cpp: top_records_first) -- are copied into LDS by every
+    // block: the kernel is bound by the number of per-lane global loads (one
+    // cache-tag lookup per lane and 16-byte load, one lookup per clock and CU), and
+    // this table serves most record fetches.  A record takes 80 bytes there, so that
+    // the lanes of one LDS read, standing on different records, spread over all banks.
+    constexpr int kTopStride = 5;    // f4 per record in the LDS table
+    __shared__ f4 top[kTop ? kTopStride * kTop : 1];
+    const uint32_t n_top = kTop ? (uint32_t)(s.n_wide < kTop ? s.n_wide : kTop) : 0u;
+    const uint32_t top_base = (uint32_t)(uintptr_t)top;   // a generic LDS address carries the LDS offset in its low half
+    if (kTop) {
+        for (uint32_t i = threadIdx.x; i < 4u * n_top; i += kBlock) top[(i >> 2) * kTopStride + (i & 3u)] = s.wide[i];
+        __syncthreads();
+    }
     const uint32_t n = n_dev ? *n_dev : n_host;
     const uint32_t lane = lane_id();
     // The LDS part of the stack is laid out [entry][thread of the block], and a lane's
     // stack pointer is kept as the BYTE offset of its next free entry from the start of
-    // that array (entry x 2048 + thread x 8): a push or pop then needs no address
+    // that array (entry x block size x 8 + thread x 8): a push or pop then needs no address
     // arithmetic beyond one add, and "is this entry in LDS" is one compare with a
     // constant for every lane.
-    constexpr uint32_t kEntryStride = 256 * sizeof(uint2);       // bytes between a lane's consecutive entries
+    constexpr uint32_t kEntryStride = kBlock * sizeof(uint2);    // bytes between a lane's consecutive entries
     constexpr uint32_t kLdsLimit = kStackLds * kEntryStride;     // offsets below this are LDS entries
     const uint32_t sp_empty = threadIdx.x * (uint32_t)sizeof(uint2);
     char *const stack_bytes = reinterpret_cast<char *>(lds_stack);
@@ -457,9 +497,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             f4 out;
             out.x = i2f(h_pos);
             out.y = h_t;
-            out.z = my_park[0 * 256];
-            out.w = my_park[1 * 256];
-            const int32_t idx = f2i(my_park[2 * 256]);
+            out.z = RT_PARK_GET(0);
+            out.w = RT_PARK_GET(1);
+            const int32_t idx = f2i(RT_PARK_GET(2));
             *reinterpret_cast<f4 *>(hits + idx) = out;
             where = kLaneIdle;
         }
@@ -474,12 +514,12 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 h_t = a.w;
                 h_lim = a.w * kTieSlack;
                 h_pos = -1;
-                my_park[0 * 256] = 0.0f;
-                my_park[1 * 256] = 0.0f;
-                my_park[2 * 256] = i2f(mine);
-                my_park[3 * 256] = b.x;
-                my_park[4 * 256] = b.y;
-                my_park[5 * 256] = b.z;
+                RT_PARK_SET(0, 0.0f);
+                RT_PARK_SET(1, 0.0f);
+                RT_PARK_SET(2, i2f(mine));
+                RT_PARK_SET(3, b.x);
+                RT_PARK_SET(4, b.y);
+                RT_PARK_SET(5, b.z);
                 sp = sp_empty;
                 stand_on(s.fast_root);
             }
@@ -502,8 +542,39 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // byte offset in 32 bits (the record table stays below 4 GB: at most one record
             // per triangle, 2^24 of them), so that the loads take the table's base from
             // scalar registers and no 64-bit address is built per lane
-            const f4 *q = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.wide) + (where << 6));
-            const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            f4 q0, q1, q2, q3;
+            if (kTop) {
+                // Lanes standing on a record of the LDS table read it from there, the others
+                // from memory, into the SAME registers, and one wait covers both: the two
+                // groups of lanes are disjoint, and a load writes only the lanes that issued
+                // it.  Written as two branches in C++, the compiler either merges them into
+                // loads through a generic pointer or makes the second branch wait for the
+                // first one's data before it issues; hence the instructions are given here.
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f w0, w1, w2, w3;
+                asm volatile("" : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3));
+                if (where < n_top) {
+                    const uint32_t at = top_base + __umul24(where, 16u * kTopStride);
+                    asm volatile("ds_read_b128 %0, %4\n\t"
+                                 "ds_read_b128 %1, %4 offset:16\n\t"
+                                 "ds_read_b128 %2, %4 offset:32\n\t"
+                                 "ds_read_b128 %3, %4 offset:48"
+                                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(at));
+                } else {
+                    const uint32_t at = where << 6;
+                    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                                 "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                                 "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+                                 "global_load_dwordx4 %3, %4, %5 offset:48"
+                                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(at), "s"(s.wide));
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                q0 = f4{w0.x, w0.y, w0.z, w0.w}; q1 = f4{w1.x, w1.y, w1.z, w1.w};
+                q2 = f4{w2.x, w2.y, w2.z, w2.w}; q3 = f4{w3.x, w3.y, w3.z, w3.w};
+            } else {
+                const f4 *q = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.wide) + (where << 6));
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
             if (COUNT) { c_nodes++; c_box += 4; if ((wave_ballot(true) & lanemask_lt()) == 0) c_wa++; }
             // frame of the record, then per child: decode the six planes with one
             // fused multiply-add each (byte -> float conversions are single
@@ -579,7 +650,9 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool two = tri_n > 1;
             // 32-bit byte offsets (at most 2^24 triangles of 48 bytes), see the descent step
             const uint32_t off_a = (uint32_t)tri_i * 48u;
-            uint32_t off_b = off_a + (two ? 48u : 0u);
+            // a lane with one triangle left reads the array's first triangle as its second:
+            // all such lanes of the wave then share one cache lookup per load
+            uint32_t off_b = two ? off_a + 48u : 0u;
             asm volatile("" : "+v"(off_b));   // stays one 32-bit offset beside the scalar base
             const f4 *qa = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_a);
             const f4 *qb = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_b);
@@ -592,7 +665,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             // the full ray only exists here
             Ray<float> r;
             r.ox = r_oxy.x; r.oy = r_oxy.y; r.oz = r_ozix.x;
-            r.dx = my_park[3 * 256]; r.dy = my_park[4 * 256]; r.dz = my_park[5 * 256];
+            r.dx = RT_PARK_GET(3); r.dy = RT_PARK_GET(4); r.dz = RT_PARK_GET(5);
             r.ix = r_ozix.y; r.iy = r_iyz.x; r.iz = r_iyz.y;
             // both triangles are evaluated side by side without early exits, then
             // offered to the hit in array order (a triangle is accepted below the
@@ -612,8 +685,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             h_pos = take_b ? tri_i + 1 : h_pos;
             h_lim = h_t * kTieSlack;
             if (take_a | take_b) {
-                my_park[0 * 256] = take_b ? ub : ua;
-                my_park[1 * 256] = take_b ? vb : va;
+                RT_PARK_SET(0, take_b ? ub : ua);
+                RT_PARK_SET(1, take_b ? vb : va);
             }
             if (tri_n <= 2) {
                 pop_next();
@@ -642,6 +715,8 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + 0, (unsigned long long)n);
     }
+#undef RT_PARK_SET
+#undef RT_PARK_GET
 }
 
 // ---------------------------------------------------------------------------
@@ -1162,6 +1237,7 @@ rt_status scene_create(const rt_mesh &mesh, const Bvh &bvh, int device, Scene **
     if (flat.fast_ok) {
         if ((st = upload(&sc->d_wide, flat.wide.data(), flat.wide.size() * 4)) != RT_OK) return st;
         sc->fast_root = flat.fast_root;
+        sc->n_wide = (int32_t)(flat.wide.size() / rtc::kWideFloats);
         sc->wide_bytes = flat.wide.size() * 4;
         std::memcpy(sc->near_lo, flat.near_lo, sizeof sc->near_lo);
         std::memcpy(sc->near_hi, flat.near_hi, sizeof sc->near_hi);
@@ -1282,6 +1358,7 @@ static DevScene dev_view(const Scene &sc) {
     d.wide = sc.d_wide;
     d.fast_root = sc.fast_root;
     d.fast_ok = sc.d_wide ? 1 : 0;
+    d.n_wide = sc.n_wide;
     return d;
 }
 
@@ -1358,11 +1435,11 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
                 case 12: hipLaunchKernelGGL((k_trace_fast<false, 12, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 16: hipLaunchKernelGGL((k_trace_fast<false, 16, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 24: hipLaunchKernelGGL((k_trace_fast<false, 24, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
-                default: hipLaunchKernelGGL((k_trace_fast<false, 8, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                default: hipLaunchKernelGGL((k_trace_fast<false, 8, true, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 }
             } else {
                 switch (sc.tune_stack) {
-                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8, false, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;

@@ -13,6 +13,10 @@
 //             child is entered without knowing its own entry distance
 //   policy 2  one entry per record as in 1, but children in distance order
 //   policy 3  octant order as in 1, but one (child, distance) entry per child
+//   policy 4  policy 0 restated in this file's loop (distance order, one entry per
+//             child), which can also count the visits of every record: how many
+//             of a ray's record fetches a table of the K most visited (or largest)
+//             records would serve
 // Output per policy: records visited and triangles fetched per ray, and the
 // hits (which must not differ in distance from policy 0's).
 #include <algorithm>
@@ -78,9 +82,9 @@ void leaf(const DevScene &s, uint32_t cur, const Ray<float> &r, Hit<float> &h, u
 
 // policies 1..3
 void traverse_variant(const DevScene &s, const Ray<float> &r, Hit<float> &h, int policy, uint64_t &records,
-                      uint64_t &tris, uint64_t &stale_children) {
+                      uint64_t &tris, uint64_t &stale_children, uint32_t *visits) {
     std::vector<Group> stack;
-    const bool octant = policy == 1 || policy == 3, per_child = policy == 3;
+    const bool octant = policy == 1 || policy == 3, per_child = policy == 3 || policy == 4;
     const float diag[3] = {r.ix < 0 ? -1.0f : 1.0f, r.iy < 0 ? -1.0f : 1.0f, r.iz < 0 ? -1.0f : 1.0f};
     uint32_t cur = s.fast_root;
     auto pop = [&]() -> uint32_t {
@@ -106,6 +110,7 @@ void traverse_variant(const DevScene &s, const Ray<float> &r, Hit<float> &h, int
     for (;;) {
         while (cur != kRefDone && (cur & kLeafBit) == 0) {
             ++records;
+            if (visits) ++visits[cur];
             Step st;
             box_step(s, cur, r, h.t, st);
             int idx[4] = {0, 1, 2, 3};
@@ -160,7 +165,7 @@ void traverse_variant(const DevScene &s, const Ray<float> &r, Hit<float> &h, int
 
 extern "C" void ordering_study(const float *wide, uint32_t fast_root, const float *tris, int32_t n_tris,
                                const float *rays8, int64_t n, int policy, float *hit_t, int32_t *hit_pos,
-                               uint64_t *out) {
+                               uint64_t *out, uint32_t *visits) {
     DevScene s{};
     s.wide = reinterpret_cast<const f4 *>(wide);
     s.fast_root = fast_root;
@@ -178,7 +183,7 @@ extern "C" void ordering_study(const float *wide, uint32_t fast_root, const floa
             records += c.nodes_visited;
             tri_count += c.tris_fetched;
         } else {
-            traverse_variant(s, r, h, policy, records, tri_count, stale);
+            traverse_variant(s, r, h, policy, records, tri_count, stale, visits);
         }
         hit_t[i] = h.t;
         hit_pos[i] = h.pos;

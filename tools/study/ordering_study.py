@@ -40,7 +40,7 @@ def main():
     rec = np.ascontiguousarray(rec, np.float32)
     tris = np.ascontiguousarray(tris, np.float32)
 
-    def run(rays, policy):
+    def run(rays, policy, visits=None):
         r8 = np.ascontiguousarray(rays.view(np.float32).reshape(-1, 8))
         t = np.zeros(len(rays), np.float32)
         pos = np.zeros(len(rays), np.int32)
@@ -48,7 +48,7 @@ def main():
         lib.ordering_study(rec.ctypes.data_as(C.c_void_p), C.c_uint32(root), tris.ctypes.data_as(C.c_void_p),
                            C.c_int32(tris.shape[0]), r8.ctypes.data_as(C.c_void_p), C.c_int64(len(rays)),
                            C.c_int(policy), t.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
-                           out.ctypes.data_as(C.c_void_p))
+                           out.ctypes.data_as(C.c_void_p), visits.ctypes.data_as(C.c_void_p) if visits is not None else None)
         return t, pos, out
 
     # ray sets: primary rays of the bench camera (a strided sample of the 4K frame), then
@@ -93,6 +93,30 @@ def main():
                 "triangles_per_ray": round(float(out[1]) / len(rays), 3),
                 "stale_children_entered_per_ray": round(float(out[2]) / len(rays), 3),
                 "hit_distance_differs_from_policy_0": int((t.view(np.uint32) != base_t.view(np.uint32)).sum())}
+    # Which share of a ray's record fetches would a table of K records in LDS serve?  Three ways to
+    # choose the K: the most visited (the best any choice can do), the largest frames (surface area of
+    # the 255-step box, known at build time), breadth-first from the root.
+    refs = rec.view(np.uint32)[:, 12:16]
+    step = rec[:, 3:6].astype(np.float64) * 255.0
+    area = step[:, 0] * step[:, 1] + step[:, 0] * step[:, 2] + step[:, 1] * step[:, 2]
+    by_area = np.argsort(-area, kind="stable")
+    bfs, frontier = [], [int(root)]
+    while frontier and len(bfs) < 8192:
+        bfs.extend(frontier)
+        kids = refs[frontier].ravel()
+        frontier = [int(k) for k in kids if k < 0x80000000]
+    by_bfs = np.array(bfs[:8192])
+    doc["top_table_share"] = {"K": [64, 128, 256, 512, 1024, 2048, 4096]}
+    for name, rays in (("primary", prim), ("bounce", bounce), ("shadow", shadow)):
+        visits = np.zeros(len(rec), np.uint32)
+        _t, _pos, out = run(rays, 4, visits)
+        total = float(visits.sum())
+        by_visits = np.argsort(-visits.astype(np.int64), kind="stable")
+        doc["top_table_share"][name] = {
+            "records_per_ray": round(total / len(rays), 3),
+            "most_visited": [round(float(visits[by_visits[:k]].sum()) / total, 3) for k in doc["top_table_share"]["K"]],
+            "largest_frames": [round(float(visits[by_area[:k]].sum()) / total, 3) for k in doc["top_table_share"]["K"]],
+            "breadth_first": [round(float(visits[by_bfs[:k]].sum()) / total, 3) for k in doc["top_table_share"]["K"]]}
     print(json.dumps(doc, indent=1))
 
 
