@@ -41,6 +41,9 @@ def main():
         "   SALU instructions per VALU instruction    %.2f" % (v["SQ_INSTS_SALU"] / v["SQ_INSTS_VALU"]),
         "   vector memory read instructions per ray   %.2f wave-level (SQ_INSTS_VMEM_RD / rays)" % (c["SQ_INSTS_VMEM_RD"] / rays),
         "   TA busy                                   %.2f   (TA_TA_BUSY_sum / (GRBM_GUI_ACTIVE / 8 x 256 CUs))" % (c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256)),
+        "   L1 lookups per ray                        %.1f   (TCP_TOTAL_CACHE_ACCESSES_sum / rays: one per lane and 16-byte load)" % (c["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays),
+        "   L1 lookups per clock and CU               %.2f   (the same / (GRBM_GUI_ACTIVE / 8 x 256 CUs))" % (c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256)),
+        "   LDS cycles lost to bank conflicts         %s" % ("%.2f of the LDS's busy cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)" % (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else "not collected"),
         "   fabric bytes per ray                      %.1f   (FETCH_SIZE + WRITE_SIZE)" % t["hbm_bytes_per_ray"],
         "   L2 hit rate                               %.2f" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]))]
     name = "k_trace_fast" if mode == "fast" else "k_trace_ref"

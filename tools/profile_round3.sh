@@ -21,7 +21,7 @@ for mode in $modes; do
   python3 tools/pmc_to_profiles.py traffic $out/fetch_$mode $out/write_$mode $out/fetch_$mode.log $wl $mode > $out/traffic_$mode.txt
   timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_WR TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum \
       -d $out/mem1_$mode --output-format csv -- python3 bench.py $common --mode $mode > $out/mem1_$mode.log 2>&1
-  timeout -s KILL 240 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum \
+  timeout -s KILL 240 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
       -d $out/mem2_$mode --output-format csv -- python3 bench.py $common --mode $mode > $out/mem2_$mode.log 2>&1
 done
 python3 tools/pmc_summary.py $out k_ > $out/pmc_all_kernels.txt
