@@ -322,6 +322,39 @@ def test_ordered_records_layout(product_lib):
     assert (((refs[leaf] >> 24) & 0x7F) <= 4).all()
 
 
+def test_ordered_records_lead_with_the_largest_frames(product_lib):
+    """The flattener puts the records with the largest frames (255-step boxes) first,
+    largest first, because the ordered kernel keeps a prefix of the array in LDS
+    (flatten.cpp: top_records_first); the others stay in depth-first order, a record's
+    first interior child right behind it."""
+    sc = scenes.soup(9000, seed=7)
+    bvh = api.Bvh.build(product_mesh(sc), True, 6, 32)
+    rec, root = bvh.flatten_ordered()
+    n = rec.shape[0]
+    assert root == 0 and n > 1024 + 100
+    ext = 255.0 * rec[:, 3:6].astype(np.float64)
+    area = ext[:, 0] * ext[:, 1] + ext[:, 0] * ext[:, 2] + ext[:, 1] * ext[:, 2]
+    top = 1024                                            # rt_core.h: kWideTopRecords
+    assert (np.diff(area[:top]) <= 0).all()
+    assert area[:top].min() >= area[top:].max()
+    refs = rec[:, 12:16].view(np.uint32)
+    interior = (refs & 0x80000000) == 0
+    # still one tree: every record but the root referenced exactly once
+    assert sorted(refs[interior].tolist()) == list(range(1, n))
+    # a parent's frame contains its children's frames, so the front is a top of the tree:
+    # every record of the front is referenced from the front
+    parent = np.zeros(n, np.int64)
+    rows = np.nonzero(interior)[0]
+    parent[refs[interior]] = rows
+    assert (parent[1:top] < top).all()
+    # behind the front: depth-first order, i.e. a record's first interior child that is
+    # not in the front follows it directly whenever the record itself is not in the front
+    deep = np.arange(top, n)
+    first_child = np.array([next((int(r) for r, i in zip(refs[k], interior[k]) if i and r >= top), -1) for k in deep])
+    has = first_child >= 0
+    assert (first_child[has] == deep[has] + 1).all()
+
+
 def test_textured_render_bit_exact(product_lib, oracle, emul):
     """map_Kd sampling of the device functions (material_diffuse) against the
     oracle's getMaterialParameters: repeat wrap incl. negative coordinates, odd
