@@ -139,11 +139,48 @@ struct Ray {
     bool sx, sy, sz;
 };
 
+// The inverse direction of a ray (ray.go:33-37), three correctly rounded
+// quotients 1 / d.  On the device a float32 component takes a short path: the
+// hardware reciprocal (1 ulp) and two Newton steps in fused arithmetic, five
+// instructions instead of the ten of the compiler's division, which also scales
+// denormal and huge operands.  The short form equals the IEEE quotient for EVERY
+// float whose magnitude lies in [2^-100, 2^100], either sign (compared
+// exhaustively on the GPU by tools/ubench/rcp_check.hip, which the GPU tests
+// run); a wave in which any lane holds a component outside that range -- zero,
+// denormal, infinite, NaN -- takes the division for all three, behind one vote.
+template <typename Real>
+RT_HD void recip3(Real x, Real y, Real z, Real &ix, Real &iy, Real &iz) {
+    ix = (Real)1.0 / x;
+    iy = (Real)1.0 / y;
+    iz = (Real)1.0 / z;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD float recip_short(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+template <>
+RT_HD void recip3<float>(float x, float y, float z, float &ix, float &iy, float &iz) {
+    ix = recip_short(x);
+    iy = recip_short(y);
+    iz = recip_short(z);
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
+    const bool plain = (ax >= 0x1p-100f) & (ax <= 0x1p100f) & (ay >= 0x1p-100f) & (ay <= 0x1p100f) &
+                       (az >= 0x1p-100f) & (az <= 0x1p100f);
+    if (__builtin_amdgcn_ballot_w64(!plain) != 0) {
+        ix = 1.0f / x;
+        iy = 1.0f / y;
+        iz = 1.0f / z;
+    }
+}
+#endif
+
 template <typename Real>
 RT_HD void ray_init(Ray<Real> &r, float ox, float oy, float oz, float dx, float dy, float dz) {
     r.ox = (Real)ox; r.oy = (Real)oy; r.oz = (Real)oz;
     r.dx = (Real)dx; r.dy = (Real)dy; r.dz = (Real)dz;
-    r.ix = (Real)1.0 / r.dx; r.iy = (Real)1.0 / r.dy; r.iz = (Real)1.0 / r.dz;
+    recip3<Real>(r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
     r.sx = r.ix < 0; r.sy = r.iy < 0; r.sz = r.iz < 0;
 }
 
@@ -172,7 +209,7 @@ RT_HD bool slab(const Ray<Real> &r, const f4 &lo, const f4 &hi, Real &otmin, Rea
 // (1 ulp) and two Newton steps in fused arithmetic, five instructions instead
 // of the ten of the compiler's division, which also scales denormal and huge
 // operands.  The short form equals the IEEE quotient for EVERY float in
-// [5e-5, 2^100] (compared exhaustively on the GPU by tools/ubench/rcp_check.hip,
+// [2^-100, 2^100] (compared exhaustively on the GPU by tools/ubench/rcp_check.hip,
 // which the GPU tests run); the cull has rejected determinants below 1e-4
 // before the quotient is used, and larger ones (or NaN) take the division.
 template <typename Real>
@@ -182,9 +219,7 @@ RT_HD Real recip_det(Real det) {
 #if defined(__HIP_DEVICE_COMPILE__)
 template <>
 RT_HD float recip_det<float>(float det) {
-    float r = __builtin_amdgcn_rcpf(det);
-    r = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
-    r = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
+    float r = recip_short(det);
     // a vote of the wave, so that the division's ten instructions sit behind a scalar
     // branch that is all but never taken instead of being computed and masked out
     const bool wide_range = !(det <= 0x1p100f);

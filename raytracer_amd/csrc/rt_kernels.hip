@@ -114,9 +114,9 @@ struct RayFeed {
     bool exhausted = false;      // the global cursor has passed the last ray
 };
 
-// Called by all lanes of the wave.  `idle` = ballot of lanes without a ray.
+// Called by all lanes of the wave.  `idle` = ballot of lanes without a ray, `is_idle` = this lane's own bit of it.
 // Returns this lane's new ray index, or -1.
-__device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint32_t n, uint64_t idle) {
+__device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint32_t n, uint64_t idle, bool is_idle) {
     if (f.pos >= f.end && !f.exhausted) {
         uint32_t base = 0;
         if (lane_id() == 0) base = atomicAdd(cursor, kRayChunk);
@@ -129,8 +129,9 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
         }
     }
     const uint32_t avail = f.end - f.pos;
-    const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
-    const bool is_idle = (idle >> lane_id()) & 1ull;
+    // rank among the idle lanes: one mbcnt pair (a 64-bit "lanes below me" mask takes a
+    // shift, a subtraction, two ands and two bit counts)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
     const int32_t mine = (is_idle && rank < avail) ? (int32_t)(f.pos + rank) : -1;
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     f.pos += n_idle < avail ? n_idle : avail;
@@ -188,7 +189,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         }
         uint64_t active = wave_ballot(idx >= 0);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
-            const int32_t mine = feed_take(feed, next, n, ~active);
+            const int32_t mine = feed_take(feed, next, n, ~active, idx < 0);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
@@ -505,12 +506,14 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         }
         uint64_t active = wave_ballot(where != kLaneIdle);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
-            const int32_t mine = feed_take(feed, next, n, ~active);
+            const int32_t mine = feed_take(feed, next, n, ~active, where == kLaneIdle);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
                 r_oxy.x = a.x; r_oxy.y = a.y; r_ozix.x = a.z;
-                r_ozix.y = 1.0f / b.x; r_iyz.x = 1.0f / b.y; r_iyz.y = 1.0f / b.z;   // ray.go:33-37
+                float inv_x, inv_y, inv_z;
+                recip3<float>(b.x, b.y, b.z, inv_x, inv_y, inv_z);   // ray.go:33-37
+                r_ozix.y = inv_x; r_iyz.x = inv_y; r_iyz.y = inv_z;
                 h_t = a.w;
                 h_lim = a.w * kTieSlack;
                 h_pos = -1;

@@ -443,11 +443,12 @@ def test_trace_call_captured_into_a_graph_replays(soup20k):
 
 
 def test_short_reciprocal_of_the_triangle_test_is_the_ieee_quotient(product_lib, gpu_device):
-    """rt_core.h: recip_det takes the hardware reciprocal plus two fused Newton
-    steps for determinants in [1e-4, 2^100] instead of the ten-instruction
-    division.  tools/ubench/rcp_check compares that sequence with 1.0f / x for
-    every float32 in [5e-5, 2^100] on the GPU it runs on: no mismatch allowed
-    (triangle.go:86 divides; the bit-exact modes need the IEEE quotient)."""
+    """rt_core.h: recip_det (1 / det of the triangle test, triangle.go:86) and recip3
+    (a ray's inverse direction, ray.go:33-37) take the hardware reciprocal plus two
+    fused Newton steps for operands of magnitude [2^-100, 2^100] instead of the
+    ten-instruction division.  tools/ubench/rcp_check compares that sequence with
+    1.0f / x for every such float32 of either sign on the GPU it runs on: no
+    mismatch allowed (the bit-exact modes need the IEEE quotient)."""
     import json
     import subprocess
     from raytracer_amd import build
@@ -456,4 +457,4 @@ def test_short_reciprocal_of_the_triangle_test_is_the_ieee_quotient(product_lib,
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.stdout, out.stderr)
     doc = json.loads(out.stdout.strip().splitlines()[-1])
-    assert doc["mismatches"] == 0 and doc["floats_checked"] > 900_000_000
+    assert doc["mismatches"] == 0 and doc["floats_checked"] > 3_300_000_000

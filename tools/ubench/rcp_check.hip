@@ -1,17 +1,21 @@
 // rcp_check.hip -- exhaustive check of a short correctly-rounded float32
 // reciprocal on the GPU it runs on.
 //
-// The triangle test divides once per triangle (1.0 / det, triangle.go:86), and
-// the bit-exact modes need the IEEE quotient.  The compiler's expansion of 1.0f / x
-// takes ten instructions because it also handles denormal and huge operands by
-// scaling.  A determinant that passes the cull (det >= 1e-4) is a normal number
-// whose reciprocal is one too, and for those five instructions suffice:
+// The triangle test divides once per triangle (1.0 / det, triangle.go:86) and a
+// ray's set-up three times (1 / direction, ray.go:33-37), and the bit-exact modes
+// need the IEEE quotient.  The compiler's expansion of 1.0f / x takes ten
+// instructions because it also handles denormal and huge operands by scaling.
+// A determinant that passes the cull (det >= 1e-4) and a direction component of
+// ordinary size are normal numbers whose reciprocals are normal too, and for
+// those five instructions suffice:
 //   r0 = v_rcp_f32(x)              (1 ulp)
 //   r1 = fma(fma(-x, r0, 1), r0, r0)
 //   q  = fma(fma(-x, r1, 1), r1, r1)
 // Markstein's theorem promises the correctly rounded quotient when r1 is within
 // an ulp; this program does not rely on it and compares q with 1.0f / x for EVERY
-// float in [lo, hi] instead.  Prints the number of mismatches (expected 0).
+// float whose magnitude lies in [2^-100, 2^100], both signs, instead (the range
+// rt_core.h's recip3 and recip_det use the short form in; outside it they divide).
+// Prints the number of mismatches (expected 0).
 //   hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt rcp_check.hip -o rcp_check
 #include <hip/hip_runtime.h>
 
@@ -39,7 +43,7 @@ __global__ void k_check(uint32_t first, uint32_t count, unsigned long long *bad,
 }
 
 int main() {
-    const float lo = 1e-4f * 0.5f, hi = 0x1p100f;      // the cull admits det >= 1e-4; well beyond it on both sides
+    const float lo = 0x1p-100f, hi = 0x1p100f;
     uint32_t blo, bhi;
     std::memcpy(&blo, &lo, 4);
     std::memcpy(&bhi, &hi, 4);
@@ -48,11 +52,13 @@ int main() {
     if (hipMalloc(&d_bad, 8) != hipSuccess || hipMalloc(&d_first, 4) != hipSuccess) return 2;
     hipMemset(d_bad, 0, 8);
     hipMemset(d_first, 0, 4);
-    hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, nullptr, blo, bhi - blo + 1, d_bad, d_first);
+    const uint32_t count = bhi - blo + 1;
+    hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, nullptr, blo, count, d_bad, d_first);                // positive
+    hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, nullptr, blo | 0x80000000u, count, d_bad, d_first);  // negative
     if (hipDeviceSynchronize() != hipSuccess) return 3;
     hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
     hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost);
-    std::printf("{\"floats_checked\": %u, \"range\": [%g, %g], \"mismatches\": %llu, \"first_bad_bits\": \"0x%08x\"}\n",
-                bhi - blo + 1, lo, hi, bad, first);
+    std::printf("{\"floats_checked\": %llu, \"range\": [%g, %g], \"signs\": \"both\", \"mismatches\": %llu, \"first_bad_bits\": \"0x%08x\"}\n",
+                2ull * count, lo, hi, bad, first);
     return bad == 0 ? 0 : 1;
 }
