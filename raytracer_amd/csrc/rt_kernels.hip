@@ -170,15 +170,17 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
     RayFeed feed;
     Ray<Real> r;
     Hit<Real> h;
-    // next node in preorder; triangles left in the passed leaf.  A lane without a ray
-    // stands past the last node with no triangles left, like a lane whose ray has just
-    // finished, so the votes below need not look at idx.
-    int32_t node = 0x7fffffff, leaf_a = 0, leaf_n = 0;
+    // Where the lane stands, in ONE register so that every vote of the wave is one
+    // compare: a node index below n_nodes -- it walks, that node is tested next; a
+    // negative value -- it holds a passed leaf (leaf_a, leaf_n: triangles left; nxt:
+    // the node to go on with afterwards); an index past the last node -- its ray is
+    // finished, or it has none (then idx is -1 as well).
+    int32_t cur = 0x7fffffff, nxt = 0, leaf_a = 0, leaf_n = 0;
     uint32_t c_nodes = 0, c_box = 0, c_fetch = 0, c_test = 0;
 
     for (;;) {
         // retire rays that walked past the last node, refill idle lanes
-        if (idx >= 0 && node >= s.n_nodes && leaf_n == 0) {
+        if (idx >= 0 && cur >= s.n_nodes) {
             f4 out;
             out.x = i2f(h.pos);
             out.y = (float)h.t;
@@ -198,8 +200,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
                 h.u = 0;
                 h.v = 0;
                 h.pos = -1;
-                node = 0;
-                leaf_n = 0;
+                cur = 0;
                 idx = mine;
             }
             active = wave_ballot(idx >= 0);
@@ -213,11 +214,12 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         // passed leaf; the phase ends once fewer than descend_min lanes still walk
         // while others wait on a leaf
         for (;;) {
-            const bool walking = node < s.n_nodes && leaf_n == 0;
+            const bool walking = (uint32_t)cur < (uint32_t)s.n_nodes;
             const uint64_t m_walk = wave_ballot(walking);
             if (m_walk == 0) break;
-            if ((int)__popcll(m_walk) < descend_min && wave_ballot(leaf_n > 0) != 0) break;
-            if (!walking) continue;
+            if ((int)__popcll(m_walk) < descend_min && wave_ballot(cur < 0) != 0) break;
+            if (walking) {
+            const int32_t node = cur;
             f4 lo, hi;
             if (TOP) {
                 // Lanes standing on a node of the LDS table read it from there, the others
@@ -262,35 +264,40 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             if (TOP) {
                 // a = next node when this one fails or is a leaf; b = leaf range or ~left child
                 if (b >= 0) {
-                    if (pass) {
+                    cur = a;
+                    if (pass && (b >> 24) > 0) {
                         leaf_a = b & 0xFFFFFF;
                         leaf_n = b >> 24;
+                        nxt = a;
+                        cur = -1;
                     }
-                    node = a;
                 } else {
                     if (COUNT && pass) c_nodes++;
-                    node = pass ? -1 - b : a;
+                    cur = pass ? -1 - b : a;
                 }
             } else if (b >= 0) {
-                if (pass) {
+                cur = node + 1;
+                if (pass && b > 0) {
                     leaf_a = a;
                     leaf_n = b;
+                    nxt = node + 1;
+                    cur = -1;
                 }
-                node = node + 1;
             } else {
                 if (COUNT && pass) c_nodes++;
-                node = pass ? node + 1 : a;
+                cur = pass ? node + 1 : a;
+            }
             }
         }
         // phase B: the leaf's triangles, in array order; ends when no lane holds a
         // leaf, or when fewer than leaf_min do while enough lanes wait to walk
         for (;;) {
-            const bool in_leaf = leaf_n > 0;
+            const bool in_leaf = cur < 0;
             const uint64_t m_leaf = wave_ballot(in_leaf);
             if (m_leaf == 0) break;
             if ((int)__popcll(m_leaf) < leaf_min &&
-                (int)__popcll(wave_ballot(node < s.n_nodes && leaf_n == 0)) >= descend_min) break;
-            if (!in_leaf) continue;
+                (int)__popcll(wave_ballot((uint32_t)cur < (uint32_t)s.n_nodes)) >= descend_min) break;
+            if (in_leaf) {
             // two triangles per step, fetched together so that their loads overlap,
             // tested in array order
             const bool two = leaf_n > 1;
@@ -317,7 +324,8 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             }
             leaf_a += 2;
             leaf_n -= 2;
-            if (leaf_n < 0) leaf_n = 0;
+            if (leaf_n <= 0) cur = nxt;
+            }
         }
     }
     if (COUNT) {
