@@ -164,7 +164,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         for (int i = threadIdx.x; i < 2 * s.n_top; i += blockDim.x) top[i] = s.linked[i];
         __syncthreads();
     }
-    const uint32_t top_base = (uint32_t)(uintptr_t)top;   // a generic LDS address carries the LDS offset in its low half
+    const uint32_t top_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)top;   // the table's offset in LDS, which the hand-written ds_read takes
     const uint32_t n = n_dev ? *n_dev : n_host;
     int32_t idx = -1;            // ray owned by this lane, -1 = idle
     RayFeed feed;
@@ -439,7 +439,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     constexpr int kTopStride = 5;    // f4 per record in the LDS table
     __shared__ f4 top[kTop ? kTopStride * kTop : 1];
     const uint32_t n_top = kTop ? (uint32_t)(s.n_wide < kTop ? s.n_wide : kTop) : 0u;
-    const uint32_t top_base = (uint32_t)(uintptr_t)top;   // a generic LDS address carries the LDS offset in its low half
+    const uint32_t top_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)top;   // the table's offset in LDS, which the hand-written ds_read takes
     if (kTop) {
         for (uint32_t i = threadIdx.x; i < 4u * n_top; i += kBlock) top[(i >> 2) * kTopStride + (i & 3u)] = s.wide[i];
         __syncthreads();
