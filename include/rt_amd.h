@@ -130,6 +130,9 @@ rt_status rt_flatten(const rt_mesh *mesh, const rt_bvh *bvh, float *nodes, float
  *           decoded boxes contain the binary tree's boxes),
  *   [12..15] child refs = record index, or for a leaf
  *           0x80000000 | count << 24 | first triangle; unused slot = 0x80000000.
+ * Order of the records: the 1024 with the largest frames (a top of the tree)
+ * first, largest first -- the traversal kernel keeps a prefix of the array in
+ * LDS --, the others depth first, a record's first interior child behind it.
  * Call with records == NULL to get the count.  *root_ref is the ref traversal
  * starts from. */
 rt_status rt_flatten_ordered(const rt_mesh *mesh, const rt_bvh *bvh, float *records,
