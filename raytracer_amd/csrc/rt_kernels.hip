@@ -1431,8 +1431,8 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const bool near_form = mode == RT_MODE_FAST_NEAR_F32;
     if (near_form) mode = RT_MODE_FAST_F32;
     const bool ordered = mode == RT_MODE_FAST_F32 && sc.d_wide;
-    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 58 : 60);
-    const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 36 : 24);
+    const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 58 : 56);
+    const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 36 : 28);
     const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 12 : 8);
     switch (mode) {
     case RT_MODE_FAST_F32:
