@@ -28,8 +28,15 @@ def last_json(path):
 def main():
     wl = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", "r03_" + wl)
+    # only this workload's entries: the other workload's may be newer here than in that run's copy
     for name in ("r03_valu_per_ray.json", "r03_traffic.json"):
-        shutil.copy(os.path.join(src, name), os.path.join(P, name))
+        new = json.load(open(os.path.join(src, name)))
+        dst = os.path.join(P, name)
+        cur = json.load(open(dst)) if os.path.exists(dst) else {}
+        cur[wl] = new[wl]
+        with open(dst, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
+            f.write("\n")
     shutil.copy(os.path.join(src, "pmc_all_kernels.txt"), os.path.join(P, f"r03_pmc_{wl}_all_kernels.txt"))
     if wl == "cfg3":
         shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r03_bench_default_kernel_stats.csv"))
