@@ -592,6 +592,29 @@ def gather_ceiling(job, W, leg):
                     "of its fetch stream the nearer cache levels absorb, it is not a fraction of a ceiling"}
 
 
+def random_gather_ceiling(job, W, leg):
+    """Beside the HBM roofline of a scene beyond the Infinity Cache: what the memory
+    system delivers to the traversal's access pattern.  rt_gather_probe chases
+    uniformly random 64-byte records through a table of this scene's size (ordered
+    view + triangles); at 64 bytes per request that rate is far below the streaming
+    peak, and it is the ceiling the kernel's fabric fetches stand against."""
+    from raytracer_amd import api
+    info = W.scene.info()
+    nbytes = info["ordered_bytes"] + info["tri_bytes"]
+    if not nbytes:
+        return None
+    recs = api.gather_probe(job.local_rank, nbytes)
+    gbps = recs * 64.0 / 1e9
+    fabric = leg["roofline"].get("achieved") if leg["roofline"].get("bound") == "hbm" else None
+    return {"table_mb": round(nbytes / 1e6, 1), "records_per_s": round(recs, 1), "GBps": round(gbps, 1),
+            "kernel_fabric_GBps": fabric,
+            "kernel_fabric_over_gather": round(fabric / gbps, 3) if fabric and gbps else None,
+            "note": "rt_gather_probe: every lane chases UNIFORMLY random 64-byte records through a table of "
+                    "the scene's size (measured by this run outside its timed region); the kernel's fabric "
+                    "bytes are the counter measurement of the roofline object (L2 hits do not count), so the "
+                    "ratio says how close its misses run to what the memory system gives scattered 64-byte reads"}
+
+
 def extra_object(W, leg):
     """One extra leg as it appears under "extra" in the line."""
     r = leg["roofline"]
@@ -605,7 +628,8 @@ def extra_object(W, leg):
                                                "rays_per_s_in_kernel", "kernel_ms_per_step",
                                                "kernel_launches_per_step", "kernel_avg_launch_ms", "nodes_per_ray",
                                                "tris_per_ray", "bytes_per_ray", "scene_mb", "lane_inst_per_ray",
-                                               "profile_head", "profile_warning")}}
+                                               "hbm_random_gather", "profile_head", "profile_warning")
+                         if k in r or k != "hbm_random_gather"}}
 
 
 def main():
@@ -623,6 +647,8 @@ def main():
         wl, roof = W.wl, leg["roofline"]
         if leg["resident"]:
             roof["l2_mall"] = gather_ceiling(job, W, leg)
+        else:
+            roof["hbm_random_gather"] = random_gather_ceiling(job, W, leg)
         out = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": leg["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -660,7 +686,10 @@ def main():
         W.release()                                  # its 192 GB of path workspace make room for the next scene's
         W = None
         W4 = Workload(job, "cfg4")
-        extra["fast_cfg4"] = extra_object(W4, run_leg(job, W4, "fast", 16, 1, 1))
+        leg4 = run_leg(job, W4, "fast", 16, 1, 1)
+        if not leg4["resident"]:
+            leg4["roofline"]["hbm_random_gather"] = random_gather_ceiling(job, W4, leg4)
+        extra["fast_cfg4"] = extra_object(W4, leg4)
         W4.release()
     if rank == 0:
         if extra:

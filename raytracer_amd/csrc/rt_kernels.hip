@@ -304,7 +304,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
             const f4 *qa, *qb;
             if (TOP) {
                 // 32-bit byte offsets beside the scalar base (triangle positions of a linked view are below 2^24)
-                const uint32_t off_a = (uint32_t)leaf_a * 48u;
+                const uint32_t off_a = __umul24((uint32_t)leaf_a, 48u);   // a 24-bit multiply is full rate, the 32-bit one a quarter
                 uint32_t off_b = off_a + (two ? 48u : 0u);
                 asm volatile("" : "+v"(off_b));
                 qa = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(s.tris) + off_a);
@@ -461,7 +461,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
     // (origin x, origin y), (origin z, 1/dir x), (1/dir y, 1/dir z)
     f2 r_oxy{0, 0}, r_ozix{0, 0}, r_iyz{0, 0};
     float h_t = 0;               // closest hit so far
-    float h_lim = 0;             // h_t * kTieSlack: entry distances up to here are still entered
+    float h_lim = 0;             // h_t * kTieSlack, kept finite: entry distances up to here are still entered
     int32_t h_pos = -1;
     // The lane's whole state is where it stands, in the form of a child reference:
     // an interior record index (>= 0 as a signed number), or leaf bit | triangles
@@ -523,7 +523,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 recip3<float>(b.x, b.y, b.z, inv_x, inv_y, inv_z);   // ray.go:33-37
                 r_ozix.y = inv_x; r_iyz.x = inv_y; r_iyz.y = inv_z;
                 h_t = a.w;
-                h_lim = a.w * kTieSlack;
+                h_lim = fminf(a.w * kTieSlack, kF32Max);
                 h_pos = -1;
                 RT_PARK_SET(0, 0.0f);
                 RT_PARK_SET(1, 0.0f);
@@ -622,8 +622,10 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
                 else slab_planes(tx, ty, tz, f_oxy, f_ozsx, f_syz, r_oxy, r_ozix, r_iyz);   \
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x);                            \
                 const float tf = fminf(fminf(tx.y, ty.y), tz.y);                            \
-                /* tn <= tf && tn <= h_lim && tf > 0 with one compare less (unused slot: inverted box) */ \
-                const bool hit = (tn <= fminf(tf, h_lim)) & (tf > 0);                       \
+                /* the box is met (unused slot: inverted box); whether it lies within reach of */ \
+                /* the hit distance is asked once per child after the sort, where the old      */ \
+                /* "was it met" compare stood, so the step has no min(tf, h_lim) per child     */ \
+                const bool hit = (tn <= tf) & (tf > 0);                                     \
                 key[k] = hit ? tn : kF32Inf;                                                \
             }
             RT_SLAB(0)
@@ -633,14 +635,15 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
 #undef RT_SLAB
 #undef RT_BYTE
             wide_sort4(key, ref);
-            // missed children carry +inf and sort last
-            if (!(key[0] < kF32Inf)) {
+            // missed children carry +inf and sort last; h_lim is finite, so one compare says
+            // both "met" and "entry distance within reach of the hit distance"
+            if (!(key[0] <= h_lim)) {
                 pop_next();
             } else {
                 // farthest first, so that the nearest of the rest is popped first
-                if (key[3] < kF32Inf) push(ref[3], key[3]);
-                if (key[2] < kF32Inf) push(ref[2], key[2]);
-                if (key[1] < kF32Inf) push(ref[1], key[1]);
+                if (key[3] <= h_lim) push(ref[3], key[3]);
+                if (key[2] <= h_lim) push(ref[2], key[2]);
+                if (key[1] <= h_lim) push(ref[1], key[1]);
                 stand_on(ref[0]);
             }
             }
@@ -694,7 +697,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
             const bool take_b = two & in_b & ((tb < h_t) | ((tb == h_t) & (tri_i + 1 < h_pos)));
             h_t = take_b ? tb : h_t;
             h_pos = take_b ? tri_i + 1 : h_pos;
-            h_lim = h_t * kTieSlack;
+            h_lim = fminf(h_t * kTieSlack, kF32Max);
             if (take_a | take_b) {
                 RT_PARK_SET(0, take_b ? ub : ua);
                 RT_PARK_SET(1, take_b ? vb : va);
