@@ -407,11 +407,14 @@ RT_HD void traverse_ordered(const DevScene &s, const Ray<float> &r, Hit<float> &
                 const float tf = fminf(fminf(tfa[0], tfa[1]), tfa[2]);
                 ref[k] = (uint32_t)f2i(q[12 + k]);
                 // an unused slot has an inverted box (tn > tf) and needs no test of its own
-                const bool hit = (tn <= fminf(tf, h.t * kTieSlack)) & (tf > 0);
+                const bool hit = (tn <= tf) & (tf > 0);
                 key[k] = hit ? tn : kF32Inf;
-                n_hit += hit ? 1 : 0;
             }
             wide_sort4(key, ref);
+            // whether a child lies within reach of the hit distance is asked after the sort, as in
+            // the kernel: missed children carry +inf, the reach is kept finite, one compare says both
+            const float reach = fminf(h.t * kTieSlack, kF32Max);
+            for (int k = 0; k < 4; ++k) n_hit += key[k] <= reach ? 1 : 0;
             if (n_hit == 0) {
                 cur = kRefDone;
                 while (sp > 0) {
