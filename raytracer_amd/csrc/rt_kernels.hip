@@ -114,18 +114,39 @@ struct RayFeed {
     bool exhausted = false;      // the global cursor has passed the last ray
 };
 
+// GUIDED instantiations of the traversal kernels (the launcher picks them for launches
+// of a few million rays) take smaller chunks towards the end of the launch: a wave whose
+// last chunk ended within one round of chunks (one chunk for every wave of the grid) of
+// the last ray asks for half a chunk, within half a round for a quarter.  The rays a
+// wave holds when the cursor runs out are what it finishes alone, at falling lane counts;
+// in a small launch that tail is most of the launch (a single batch of 2 M primary rays:
+// 1.30 instead of 1.76 ms in the reference-order kernel, 0.73 instead of 0.81 ms in the
+// ordered one), in a launch of 100 M rays it is nothing.  Large launches run the plain
+// instantiation, whose code is untouched: the same logic chosen by a kernel argument
+// cost them 0.5 % (one more scalar argument and a branch in kernels this close to their
+// limit), small chunks throughout cost 20 % (the cursor's atomic has a rate).
+template <bool GUIDED>
+__device__ __forceinline__ uint32_t feed_chunk(const RayFeed &f, uint32_t n) {
+    if (!GUIDED) return kRayChunk;
+    const uint32_t round = gridDim.x * (blockDim.x >> 6) * kRayChunk;
+    const uint32_t left = n > f.end ? n - f.end : 0u;   // the cursor is at or past this wave's last chunk
+    return left < round / 2 ? kRayChunk / 4 : (left < round ? kRayChunk / 2 : kRayChunk);
+}
+
 // Called by all lanes of the wave.  `idle` = ballot of lanes without a ray, `is_idle` = this lane's own bit of it.
 // Returns this lane's new ray index, or -1.
+template <bool GUIDED = false>
 __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint32_t n, uint64_t idle, bool is_idle) {
     if (f.pos >= f.end && !f.exhausted) {
+        const uint32_t want = feed_chunk<GUIDED>(f, n);
         uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(cursor, kRayChunk);
+        if (lane_id() == 0) base = atomicAdd(cursor, want);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n) {
             f.exhausted = true;
         } else {
             f.pos = base;
-            f.end = (n - base < kRayChunk) ? n : base + kRayChunk;
+            f.end = (n - base < want) ? n : base + want;
         }
     }
     const uint32_t avail = f.end - f.pos;
@@ -154,7 +175,7 @@ __device__ __forceinline__ int32_t feed_take(RayFeed &f, uint32_t *cursor, uint3
 constexpr int kTopNodes = 2560;
 constexpr int kTopBlock = 1024;
 
-template <typename Real, bool COUNT, bool TOP>
+template <typename Real, bool COUNT, bool TOP, bool GUIDED = false>
 __global__ void __launch_bounds__(TOP ? kTopBlock : 256)
 k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
@@ -191,7 +212,7 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         }
         uint64_t active = wave_ballot(idx >= 0);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
-            const int32_t mine = feed_take(feed, next, n, ~active, idx < 0);
+            const int32_t mine = feed_take<GUIDED>(feed, next, n, ~active, idx < 0);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
@@ -411,7 +432,7 @@ __device__ __forceinline__ void slab_planes_near(f2 &tx, f2 &ty, f2 &tz, f2 d_xy
         : "v"(d_xy), "v"(d_zsx), "v"(f_syz), "v"(r_ozix), "v"(r_iyz));
 }
 
-template <bool COUNT, int kStackLds, bool NEAR = false, int kTop = 0>
+template <bool COUNT, int kStackLds, bool NEAR = false, int kTop = 0, bool GUIDED = false>
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
@@ -514,7 +535,7 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         }
         uint64_t active = wave_ballot(where != kLaneIdle);
         if (!(feed.exhausted && feed.pos >= feed.end) && (int)__popcll(active) < refill_below) {
-            const int32_t mine = feed_take(feed, next, n, ~active, where == kLaneIdle);
+            const int32_t mine = feed_take<GUIDED>(feed, next, n, ~active, where == kLaneIdle);
             if (mine >= 0) {
                 const f4 *rp = reinterpret_cast<const f4 *>(rays + mine);
                 const f4 a = rp[0], b = rp[1];
@@ -1437,6 +1458,10 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
     const int t_refill = sc.tune_refill > 0 ? sc.tune_refill : (ordered ? 58 : 56);
     const int t_desc = sc.tune_descend_min > 0 ? sc.tune_descend_min : (ordered ? 36 : 28);
     const int t_leaf = sc.tune_leaf_min > 0 ? sc.tune_leaf_min : (ordered ? 12 : 8);
+    // launches of 1 M to 32 M ray slots run the GUIDED instantiation (smaller chunks towards the end, feed_chunk);
+    // below that a launch is a few chunks per wave anyway and four times the atomics show (the 97 k-sample tiles of
+    // the Cornell preset: 18.1 -> 20.7 ms per frame)
+    const bool guided = n_host >= ((size_t)1 << 20) && n_host <= ((size_t)1 << 25);
     switch (mode) {
     case RT_MODE_FAST_F32:
         if (sc.d_wide) {
@@ -1449,11 +1474,17 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
                 case 12: hipLaunchKernelGGL((k_trace_fast<false, 12, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 16: hipLaunchKernelGGL((k_trace_fast<false, 16, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 24: hipLaunchKernelGGL((k_trace_fast<false, 24, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
-                default: hipLaunchKernelGGL((k_trace_fast<false, 8, true, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                default:
+                    if (guided) hipLaunchKernelGGL((k_trace_fast<false, 8, true, kFastTopRecords, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                    else hipLaunchKernelGGL((k_trace_fast<false, 8, true, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                    break;
                 }
             } else {
                 switch (sc.tune_stack) {
-                case 8: hipLaunchKernelGGL((k_trace_fast<false, 8, false, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
+                case 8:
+                    if (guided) hipLaunchKernelGGL((k_trace_fast<false, 8, false, kFastTopRecords, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                    else hipLaunchKernelGGL((k_trace_fast<false, 8, false, kFastTopRecords>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf);
+                    break;
                 case 12: hipLaunchKernelGGL((k_trace_fast<false, 12>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 case 24: hipLaunchKernelGGL((k_trace_fast<false, 24>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
                 default: hipLaunchKernelGGL((k_trace_fast<false, 16>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, rb, t_desc, t_leaf); break;
@@ -1468,14 +1499,14 @@ rt_status launch_trace(Scene &sc, const rt_ray *d_rays, size_t n_host, const uin
         if (d_counters)
             { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
-            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
+            { if (d.linked && guided) hipLaunchKernelGGL((k_trace_ref<float, false, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else if (d.linked) hipLaunchKernelGGL((k_trace_ref<float, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<float, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         break;
     case RT_MODE_FP64:
         if (d.linked) { block = dim3(kTopBlock); grid = dim3((grid.x * 256 + kTopBlock - 1) / kTopBlock); }
         if (d_counters)
             { if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, true, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         else
-            { if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
+            { if (d.linked && guided) hipLaunchKernelGGL((k_trace_ref<double, false, true, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else if (d.linked) hipLaunchKernelGGL((k_trace_ref<double, false, true>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); else hipLaunchKernelGGL((k_trace_ref<double, false, false>), grid, block, 0, stream, d, d_rays, d_hits, n32, d_n, cursor, d_counters, t_refill, t_desc, t_leaf); }
         break;
     default:
         return fail(RT_ERR_INVALID, "unknown traversal mode " + std::to_string(mode));
