@@ -179,7 +179,7 @@ template <typename Real, bool COUNT, bool TOP, bool GUIDED = false>
 __global__ void __launch_bounds__(TOP ? kTopBlock : 256)
 k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
             uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-            unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
+            unsigned long long *counters, int refill_below, int descend_min_full, int leaf_min_full) {
     __shared__ f4 top[TOP ? 2 * kTopNodes : 1];
     if (TOP) {
         for (int i = threadIdx.x; i < 2 * s.n_top; i += blockDim.x) top[i] = s.linked[i];
@@ -229,6 +229,16 @@ k_trace_ref(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hi
         if (active == 0) {
             if (feed.exhausted && feed.pos >= feed.end) break;
             continue;   // the chunk ran dry in the middle of a refill: take the next one
+        }
+        // GUIDED instantiations: the phase thresholds scale with the lanes alive once the wave
+        // has shrunk (see k_trace_fast)
+        int descend_min = descend_min_full, leaf_min = leaf_min_full;
+        if (GUIDED) {
+            const int n_alive = (int)__popcll(active);
+            if (n_alive < 48) {
+                descend_min = (n_alive * descend_min_full + 63) >> 6;
+                leaf_min = (n_alive * leaf_min_full + 63) >> 6;
+            }
         }
 
         // phase A: walk boxes in the reference's order until this lane stands on a
@@ -436,7 +446,7 @@ template <bool COUNT, int kStackLds, bool NEAR = false, int kTop = 0, bool GUIDE
 __global__ void __launch_bounds__(256)
 k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ hits,
              uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t *next,
-             unsigned long long *counters, int refill_below, int descend_min, int leaf_min) {
+             unsigned long long *counters, int refill_below, int descend_min_full, int leaf_min_full) {
     constexpr int kStackSpill = kStackTotal - kStackLds;
     constexpr int kBlock = 256;
     __shared__ uint2 lds_stack[kBlock * kStackLds];
@@ -560,6 +570,18 @@ k_trace_fast(DevScene s, const rt_ray *__restrict__ rays, rt_hit *__restrict__ h
         if (active == 0) {
             if (feed.exhausted && feed.pos >= feed.end) break;
             continue;   // the chunk ran dry in the middle of a refill: take the next one
+        }
+        // GUIDED instantiations (small launches, which are mostly drain): the two phase
+        // thresholds are shares of a FULL wave; once the queue has run dry and the wave has
+        // shrunk, fixed numbers would end the descent phase at the first lane that reaches a
+        // leaf and never end the leaf phase early, so they scale with the lanes alive.
+        int descend_min = descend_min_full, leaf_min = leaf_min_full;
+        if (GUIDED) {
+            const int n_alive = (int)__popcll(active);
+            if (n_alive < 48) {
+                descend_min = (n_alive * descend_min_full + 63) >> 6;
+                leaf_min = (n_alive * leaf_min_full + 63) >> 6;
+            }
         }
 
         // phase A: lanes standing on an interior record descend.  The phase ends
